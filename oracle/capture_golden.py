@@ -1,0 +1,242 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation in the build container.
+
+Run here only:  python -m oracle.capture_golden   (needs /root/reference; never runs on the GPU box)
+
+The reference (pure Python/PyTorch) is imported from /root/reference/src with a stub `clip` module
+(CLIP's package and weights are absent and its output is an *input* of the path).
+Weights come from oracle.det (seed-free recipe) and are loaded into the reference module through its own
+load_state_dict; inputs / noise come from the same recipe, so fixtures hold only small inputs and the
+reference's outputs.  Nothing from /root/reference is copied: fixtures are data.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import det
+from . import mdm_oracle as O
+
+REF_SRC = "/root/reference/src"
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _install_clip_stub():
+    clip = types.ModuleType("clip")
+    clip.model = types.ModuleType("clip.model")
+
+    class _FakeClip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._emb = None
+
+        def encode_text(self, tokens):
+            return self._emb
+
+    clip.load = lambda *a, **k: (_FakeClip(), None)
+    clip.model.convert_weights = lambda m: None
+    clip.tokenize = lambda texts, context_length=77, truncate=True: torch.zeros(
+        (len(texts), context_length), dtype=torch.long
+    )
+    sys.modules["clip"] = clip
+    sys.modules["clip.model"] = clip.model
+
+
+def _ref_model(arch: O.Arch, sd):
+    from oakink2_tamf.model.interaction_segment_mdm import InterationSegmentMDM
+
+    m = InterationSegmentMDM(
+        input_dim=arch.input_dim,
+        obj_input_dim=arch.obj_input_dim,
+        hand_shape_dim=arch.hand_shape_dim,
+        obj_embed_dim=arch.obj_embed_dim,
+        latent_dim=arch.latent_dim,
+        ff_size=arch.ff_size,
+        num_layers=arch.num_layers,
+        num_heads=arch.num_heads,
+        dropout=0.1,
+        activation="gelu",
+    )
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("clip_model") for k in missing), missing
+    m.eval()  # returns None in the reference (interaction_segment_mdm.py:176-178)
+    return m
+
+
+def _ref_batch(cond, m):
+    m.clip_model._emb = cond["text_embedding"]
+    B = cond["text_embedding"].shape[0]
+    return {
+        "text": ["x"] * B,
+        "hand_side": cond["hand_side"],
+        "shape": cond["shape"],
+        "obj_embedding": cond["obj_embedding"],
+        "obj_traj": cond["obj_traj"],
+    }
+
+
+def _cond_np(cond):
+    return {
+        "text_embedding": cond["text_embedding"].numpy(),
+        "hand_side": np.array([0 if h == "rh" else 1 for h in cond["hand_side"]], dtype=np.uint8),
+        "shape": cond["shape"].numpy(),
+        "obj_embedding": cond["obj_embedding"].numpy(),
+        "obj_traj": cond["obj_traj"].numpy(),
+    }
+
+
+def capture_schedule():
+    from oakink2_tamf.model.diffusion_util import create_gaussian_diffusion
+
+    out = {}
+    for n in (1000, 50):
+        dif = create_gaussian_diffusion(diffusion_steps=n, noise_schedule="cosine")
+        tab = O.make_tables(n, "cosine")
+        for k in (
+            "betas",
+            "alphas_cumprod",
+            "alphas_cumprod_prev",
+            "posterior_variance",
+            "posterior_log_variance_clipped",
+            "posterior_mean_coef1",
+            "posterior_mean_coef2",
+            "sqrt_alphas_cumprod",
+            "sqrt_one_minus_alphas_cumprod",
+        ):
+            ref = np.asarray(getattr(dif, k), dtype=np.float64)
+            mine = getattr(tab, k)
+            err = np.max(np.abs(ref - mine))
+            print(f"schedule N={n} {k}: oracle-vs-reference max abs err {err:.3e}")
+            out[f"n{n}/{k}"] = ref
+        assert dif.timestep_map == list(range(n))
+    np.savez_compressed(os.path.join(OUT_DIR, "schedule.npz"), **out)
+
+
+def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfinite=False):
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    m = _ref_model(arch, sd)
+    cond = O.det_cond(B, T, nobj=nobj, tag=f"{name}/c", arch=arch)
+    x = torch.from_numpy(det.det_normal(f"{name}/x", (B, arch.input_dim, 1, T)))
+    if nonfinite:
+        # exercise the three nan_to_num sites (interaction_segment_mdm.py:158,166,173)
+        cond["text_embedding"][0, 3] = float("nan")
+        x[1, 5, 0, 2] = float("inf")
+    batch = _ref_batch(cond, m)
+    fix = {"x": x.numpy(), "B": B, "T": T, "nobj": nobj, "ts": np.array(ts, dtype=np.int64)}
+    fix.update({f"cond/{k}": v for k, v in _cond_np(cond).items()})
+    with torch.no_grad():
+        for t in ts:
+            tt = torch.full((B,), t, dtype=torch.long)
+            ref = m(x, tt, batch)
+            mine = O.denoiser_forward(sd, arch, x, tt, cond)
+            mine64 = O.denoiser_forward(sd, arch, x, tt, cond, dtype=torch.float64)
+            e32 = (ref - mine).abs().max().item()
+            e64 = (ref.double() - mine64).abs().max().item()
+            print(f"forward {name} t={t}: |ref-oracle32|={e32:.3e} |ref-oracle64|={e64:.3e} |ref|max={ref.abs().max():.3f}")
+            fix[f"out/t{t}"] = ref.numpy()
+        # per-sample distinct timesteps in one call (training-style call pattern, launch/train.py:518-524)
+        tt = torch.tensor([ts[i % len(ts)] for i in range(B)], dtype=torch.long)
+        fix["ts_mixed"] = tt.numpy()
+        fix["out/mixed"] = m(x, tt, batch).numpy()
+    np.savez_compressed(os.path.join(OUT_DIR, f"forward_{name}.npz"), **fix)
+
+
+def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_noise: bool, dump_steps=None):
+    from oakink2_tamf.model.diffusion_util import create_gaussian_diffusion
+    from oakink2_tamf.model.diffusion import gaussian_diffusion as gd
+
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    m = _ref_model(arch, sd)
+    cond = O.det_cond(B, T, tag=f"{name}/c", arch=arch)
+    batch = _ref_batch(cond, m)
+    shape = (B, arch.input_dim, 1, T)
+    dif = create_gaussian_diffusion(diffusion_steps=steps, noise_schedule="cosine")
+
+    calls = {"k": 0}
+    draws = []
+
+    def draw(k):
+        z = torch.from_numpy(det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape))
+        return z
+
+    class _ThProxy:
+        """torch look-alike handed to the reference module so that its th.randn / th.randn_like calls
+        (gaussian_diffusion.py:604,448) return the recipe's draws in call order."""
+
+        def __getattr__(self, a):
+            return getattr(torch, a)
+
+        def randn(self, *s, **kw):
+            k = calls["k"]
+            calls["k"] += 1
+            z = draw(k)
+            draws.append(z)
+            return z
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    real_th = gd.th
+    gd.th = _ThProxy()
+    try:
+        with torch.no_grad():
+            res = dif.p_sample_loop(
+                m, shape, clip_denoised=False, model_kwargs={"batch": batch}, dump_steps=dump_steps
+            )
+    finally:
+        gd.th = real_th
+    assert calls["k"] == steps + 1
+    tab = O.make_tables(steps, "cosine")
+    fix = {"B": B, "T": T, "steps": steps}
+    fix.update({f"cond/{k}": v for k, v in _cond_np(cond).items()})
+    if dump_steps is not None:
+        dump_ref = res
+        dump_mine: list = []
+        O.sample_loop(sd, arch, tab, cond, shape, draw, dump=dump_mine)
+        for j, s in enumerate(dump_steps):
+            e = (dump_ref[j] - dump_mine[s]).abs().max().item()
+            print(f"loop {name}: dump step {s}: |ref-oracle32| = {e:.3e}")
+            fix[f"dump/{s}"] = dump_ref[j].numpy()
+        fix["dump_steps"] = np.array(dump_steps)
+        final = dump_ref[-1]
+    else:
+        final = res
+        mine = O.sample_loop(sd, arch, tab, cond, shape, draw)
+        mine64 = O.sample_loop(sd, arch, tab, cond, shape, draw, dtype=torch.float64)
+        print(
+            f"loop {name} ({steps} steps): |ref-oracle32|={(final - mine).abs().max():.3e} "
+            f"|ref-oracle64|={(final.double() - mine64).abs().max():.3e} |ref|mean={final.abs().mean():.3f}"
+        )
+    fix["final"] = final.numpy()
+    if store_noise:
+        fix["draws"] = np.stack([d.numpy() for d in draws], axis=0)
+    np.savez_compressed(os.path.join(OUT_DIR, f"loop_{name}.npz"), **fix)
+
+
+def main():
+    assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
+    _install_clip_stub()
+    sys.path.insert(0, REF_SRC)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    torch.set_num_threads(8)
+    capture_schedule()
+    capture_forward("tiny", O.ARCH_TINY, B=2, T=16, ts=[0, 1, 500, 999])
+    capture_forward("tiny_ragged", O.ARCH_TINY, B=3, T=21, ts=[7], nobj=3)
+    capture_forward("tiny_nonfinite", O.ARCH_TINY, B=2, T=16, ts=[10], nonfinite=True)
+    capture_forward("arch_mdm", O.ARCH_MDM, B=2, T=16, ts=[0, 999])
+    capture_forward("arch_mdm_l", O.ARCH_MDM_L, B=2, T=16, ts=[0, 500])
+    capture_forward("arch_mdm_l_t196", O.ARCH_MDM_L, B=1, T=196, ts=[250])
+    # one p_sample step + short loops with the draws stored (torch-RNG independent)
+    capture_loop("tiny_10", O.ARCH_TINY, B=2, T=16, steps=10, store_noise=True, dump_steps=list(range(10)))
+    # BASELINE.json configs[0]: arch_mdm, B=4, T=64, 50 DDPM steps (noise from the det recipe)
+    capture_loop("arch_mdm_b4_t64_50", O.ARCH_MDM, B=4, T=64, steps=50, store_noise=False)
+    # full-length loop on the tiny arch
+    capture_loop("tiny_1000", O.ARCH_TINY, B=2, T=16, steps=1000, store_noise=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""CPU: the oracle against every golden vector captured from the reference (oracle/capture_golden.py).
+
+Tolerances (fp32): single forward 1e-5 abs (observed <= 1.6e-6); loops 2e-5 abs (observed <= 1.7e-6).
+Schedule tables are float64 and must match to 1e-15 (observed 0)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cond, load_golden
+from oracle import det
+from oracle import mdm_oracle as O
+
+ARCHS = {
+    "tiny": O.ARCH_TINY,
+    "tiny_ragged": O.ARCH_TINY,
+    "tiny_nonfinite": O.ARCH_TINY,
+    "arch_mdm": O.ARCH_MDM,
+    "arch_mdm_l": O.ARCH_MDM_L,
+    "arch_mdm_l_t196": O.ARCH_MDM_L,
+}
+
+
+@pytest.mark.parametrize("n", [1000, 50])
+def test_schedule_tables(n):
+    fix = load_golden("schedule.npz")
+    tab = O.make_tables(n, "cosine")
+    for k in (
+        "betas",
+        "alphas_cumprod",
+        "alphas_cumprod_prev",
+        "posterior_variance",
+        "posterior_log_variance_clipped",
+        "posterior_mean_coef1",
+        "posterior_mean_coef2",
+    ):
+        np.testing.assert_allclose(getattr(tab, k), fix[f"n{n}/{k}"], rtol=0, atol=1e-15)
+
+
+def test_schedule_anchors():
+    # SURVEY.md 8(a) a1/a2 anchor values
+    tab = O.make_tables(1000, "cosine")
+    assert abs(tab.betas[0] - 4.1284224822e-05) < 1e-14
+    assert abs(tab.betas[999] - 0.999) < 1e-12
+    assert abs(tab.alphas_cumprod[999] - 2.4287669070e-09) < 1e-17
+    assert abs(tab.posterior_mean_coef1[1] - 0.5277814093) < 1e-9
+    assert abs(tab.posterior_mean_coef2[500] - 0.9953562795) < 1e-9
+    assert tab.posterior_mean_coef1[0] == 1.0 and tab.posterior_mean_coef2[0] == 0.0
+
+
+@pytest.mark.parametrize("name", list(ARCHS))
+def test_forward_matches_reference(name):
+    fix = load_golden(f"forward_{name}.npz")
+    arch = ARCHS[name]
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    x = torch.from_numpy(fix["x"])
+    B = x.shape[0]
+    for t in fix["ts"]:
+        out = O.denoiser_forward(sd, arch, x, torch.full((B,), int(t), dtype=torch.long), cond)
+        ref = fix[f"out/t{int(t)}"]
+        assert np.isfinite(out.numpy()).all()
+        np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=1e-5)
+    out = O.denoiser_forward(sd, arch, x, torch.from_numpy(fix["ts_mixed"]), cond)
+    np.testing.assert_allclose(out.numpy(), fix["out/mixed"], rtol=0, atol=1e-5)
+
+
+def test_hand_side_rejects_unknown():
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch)
+    cond = O.det_cond(1, 8, arch=arch)
+    cond["hand_side"] = ["both"]
+    with pytest.raises(ValueError):
+        O.denoiser_forward(sd, arch, torch.zeros(1, 99, 1, 8), torch.zeros(1, dtype=torch.long), cond)
+
+
+def test_loop_tiny_10_every_step():
+    fix = load_golden("loop_tiny_10.npz")
+    arch = O.ARCH_TINY
+    name = "tiny_10"
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    draws = torch.from_numpy(fix["draws"])
+    # the stored draws are what the recipe regenerates
+    np.testing.assert_array_equal(
+        draws[3].numpy(), det.det_normal(det.step_noise_tag(f"{name}/eps", 3), draws[3].shape)
+    )
+    dump = []
+    tab = O.make_tables(10, "cosine")
+    O.sample_loop(sd, arch, tab, cond, tuple(draws[0].shape), lambda k: draws[k], dump=dump)
+    for s in fix["dump_steps"]:
+        np.testing.assert_allclose(dump[int(s)].numpy(), fix[f"dump/{int(s)}"], rtol=0, atol=2e-5)
+
+
+def test_loop_config0_arch_mdm_b4_t64_50():
+    """BASELINE.json configs[0]: arch_mdm, B=4, T=64, 50 DDPM steps (reference CPU path)."""
+    fix = load_golden("loop_arch_mdm_b4_t64_50.npz")
+    name = "arch_mdm_b4_t64_50"
+    arch = O.ARCH_MDM
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (4, 99, 1, 64)
+    tab = O.make_tables(50, "cosine")
+    out = O.sample_loop(
+        sd, arch, tab, cond, shape, lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape))
+    )
+    np.testing.assert_allclose(out.numpy(), fix["final"], rtol=0, atol=2e-5)
+
+
+def test_loop_tiny_1000():
+    fix = load_golden("loop_tiny_1000.npz")
+    name = "tiny_1000"
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 16)
+    tab = O.make_tables(1000, "cosine")
+    out = O.sample_loop(
+        sd, arch, tab, cond, shape, lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape))
+    )
+    np.testing.assert_allclose(out.numpy(), fix["final"], rtol=0, atol=2e-5)
+
+
+def test_final_step_is_pure_x0_prediction():
+    # coef1[0] = 1, coef2[0] = 0, no noise at i = 0  
+    tab = O.make_tables(50, "cosine")
+    x = torch.randn(2, 99, 1, 8)
+    x0 = torch.randn(2, 99, 1, 8)
+    out = O.ddpm_step(tab, x, x0, 0, torch.randn(2, 99, 1, 8))
+    np.testing.assert_array_equal(out.numpy(), x0.numpy())
+
+
+def test_philox_known_answer():
+    # Random123 kat_vectors: philox4x32-10, counter = key = 0 / all ones / pi digits
+    z = np.zeros(1, dtype=np.uint32)
+    r = O.philox4x32_10(z, z, z, z, 0, 0)
+    assert [int(v[0]) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = np.full(1, 0xFFFFFFFF, dtype=np.uint32)
+    r = O.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(v[0]) for v in r] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    c = [np.array([v], dtype=np.uint32) for v in (0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344)]
+    r = O.philox4x32_10(*c, 0xA4093822, 0x299F31D0)
+    assert [int(v[0]) for v in r] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_philox_normal_moments_and_shard_independence():
+    a = O.philox_normal(7, np.arange(8), 3, 99, 64)
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02
+    b = O.philox_normal(7, np.arange(4, 8), 3, 99, 64)
+    np.testing.assert_array_equal(a[4:], b)
