@@ -1,0 +1,150 @@
+/*
+ * tamf_hip.h - C-ABI of the MI355X (gfx950) MF-MDM denoiser + DDPM sampler library (libtamf_hip.so).
+ *
+ * The reference (oakink/OakInk2-TaMF) is pure Python/PyTorch and has no FFI layer; the drop-in boundary
+ * of this path is its two Python call contracts.  Each entry point below names the
+ * reference interface it stands under (paths relative to src/oakink2_tamf/ of the reference):
+ *
+ *   model(x, ts, batch=...)            model/interaction_segment_mdm.py:134-174   -> tamf_set_cond + tamf_denoise
+ *   diffusion.p_sample_loop(...)       model/diffusion/gaussian_diffusion.py:506-640 -> tamf_sample_loop
+ *   GaussianDiffusion.p_sample         model/diffusion/gaussian_diffusion.py:412-460 -> tamf_ddpm_step
+ *   create_gaussian_diffusion tables   model/diffusion_util.py:5-31, gaussian_diffusion.py:116-161 -> tamf_set_schedule
+ *   load_state_dict(torch.load(ckpt))  launch/sample.py:190-192, util/state_util.py:22-39 -> tamf_load_weight / tamf_finalize_weights
+ *   SegmentRefineModel.forward trunk   model/segment_refine_model.py:175-217      -> tamf_refine
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative tamf_status; the message of the
+ *     last failure is available from tamf_last_error(ctx) (or tamf_last_error(NULL) for ctx-less failures).
+ *     Nothing throws across the ABI.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors' data_ptr());
+ *     "host" pointers are host memory.  The library owns weights, workspaces and hipGraphs.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns without
+ *     synchronising (exceptions are stated per function).  A context is not thread-safe; contexts on
+ *     different devices are independent.
+ *   - tensors use the reference's layouts: x / x0 / noise are (B, input_dim, 1, T) float32 contiguous.
+ */
+#ifndef TAMF_HIP_H
+#define TAMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tamf_ctx tamf_ctx;
+
+typedef enum tamf_status {
+  TAMF_OK = 0,
+  TAMF_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  TAMF_ERR_STATE = -2,     /* call order violated (weights not finalised, cond not set, ...) */
+  TAMF_ERR_HIP = -3,       /* a HIP runtime call failed */
+  TAMF_ERR_MISSING = -4,   /* a required checkpoint tensor was not loaded */
+  TAMF_ERR_NOMEM = -5
+} tamf_status;
+
+/* arithmetic mode of the MFMA contractions (everything else - residual stream, LayerNorm, softmax,
+ * DDPM state - is float32 in every mode) */
+typedef enum tamf_precision {
+  TAMF_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate (parity mode) */
+  TAMF_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate */
+  TAMF_PREC_BF16X3 = 2  /* split-bf16 (hi+lo) operands, 3 bf16 MFMAs per product: ~2^-17 relative operand error */
+} tamf_precision;
+
+typedef enum tamf_model_kind {
+  TAMF_KIND_G = 0, /* InterationSegmentMDM (5 prefix tokens: t, text, side, shape, obj) */
+  TAMF_KIND_R = 1  /* SegmentRefineModel trunk (3 prefix tokens; h2o distance feature; residual output) */
+} tamf_model_kind;
+
+/* keys of config/arch_*.yml `model:` (launch/param/model.py:14-87) + the two constants of the modules */
+typedef struct tamf_arch {
+  int32_t input_dim;      /* 99  */
+  int32_t obj_input_dim;  /* 9   */
+  int32_t hand_shape_dim; /* 10  */
+  int32_t obj_embed_dim;  /* 768 */
+  int32_t latent_dim;     /* 256 (arch_mdm, arch_refine) / 512 (arch_mdm_l); supported: 128, 256, 512 */
+  int32_t ff_size;        /* 1024 / 2048; multiple of 128 */
+  int32_t num_layers;     /* 8 */
+  int32_t num_heads;      /* latent_dim / num_heads must be 64 or 128 */
+  int32_t clip_dim;       /* 512 (interaction_segment_mdm.py:25) */
+  int32_t h2o_dim;        /* 778 (segment_refine_model.py:267-279); R only */
+  int32_t kind;           /* tamf_model_kind */
+} tamf_arch;
+
+/* Create a context on `device` able to run up to max_batch clips of up to max_frames frames. */
+int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames, int32_t precision,
+                    int32_t device, tamf_ctx** out);
+void tamf_ctx_destroy(tamf_ctx* ctx);
+const char* tamf_last_error(const tamf_ctx* ctx);
+
+/* One call per checkpoint tensor (SURVEY.md A.2 key set; host float32, row-major, `shape[ndim]`).
+ * Unknown names are ignored (strict=False semantics of launch/sample.py:190-192; returns 0),
+ * a known name with a wrong shape is TAMF_ERR_INVALID. */
+int tamf_load_weight(tamf_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* Repack into kernel layouts (operand precision, fused input weights, timestep-embedding table for
+ * t in [0, max_timesteps)).  Synchronises `stream`.  TAMF_ERR_MISSING names the first absent tensor. */
+int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream);
+
+/* float64 tables of GaussianDiffusion.__init__ for the n_steps-step process; they are cast to float32
+ * exactly where the reference casts them (gaussian_diffusion.py:1275). */
+int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* posterior_mean_coef1,
+                      const double* posterior_mean_coef2, const double* posterior_log_variance_clipped);
+
+/* Conditioning of one batch (the `batch` dict of model.forward, CLIP output supplied as text_embedding):
+ *   text_emb_dev  (B, clip_dim) f32 [G only, NULL for R]      hand_side_host (B,) uint8: 0 = "rh", 1 = "lh"
+ *   shape_dev     (B, T, hand_shape_dim) f32                  obj_emb_dev    (B, nobj, obj_embed_dim) f32
+ *   obj_traj_dev  (B, nobj, T, obj_input_dim) f32
+ * Runs the step-invariant precompute (prefix tokens 1..4, object half of input_merge.0) on `stream`.
+ * A hand_side value other than 0/1 is TAMF_ERR_INVALID (the reference raises ValueError, :284). */
+int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const float* text_emb_dev,
+                  const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
+                  const float* obj_traj_dev, void* stream);
+
+/* x0_hat = G(x_t, t | cond).  x_dev, x0_out_dev: (B, input_dim, 1, T) f32; t_dev: (B,) int64 device
+ * (values in [0, max_timesteps)). */
+int tamf_denoise(tamf_ctx* ctx, const float* x_dev, const int64_t* t_dev, float* x0_out_dev, void* stream);
+
+/* One reverse step x_{t-1} = coef1[t] x0 + coef2[t] x_t + [t != 0] exp(0.5 logvar[t]) eps, elementwise over
+ * n float32 values.  noise_dev may be NULL only when t == 0. */
+int tamf_ddpm_step(tamf_ctx* ctx, const float* x_t_dev, const float* x0_dev, int32_t t, const float* noise_dev,
+                   float* x_out_dev, int64_t n, void* stream);
+
+/* The full reverse loop x_T -> x_0 (n_steps of the schedule, t = n_steps-1 .. 0), hipGraph-replayed.
+ *   noise_dev != NULL : (n_steps + 1, B, input_dim, 1, T) f32 - draw 0 is x_T, draw k the eps of the k-th
+ *                       step, i.e. the reference's th.randn / th.randn_like call order
+ *                       (gaussian_diffusion.py:604,448)  [parity mode]
+ *   noise_dev == NULL : Philox4x32-10 + Box-Muller on device, keyed (seed, clip_id_base + b, draw, element),
+ *                       so a clip's noise does not depend on how a batch is sharded  [throughput mode]
+ * dump_dev (optional): (n_steps, B, input_dim, 1, T) f32 receives x after every step (dump_steps of the reference).
+ * use_graph = 0 issues plain launches (debugging). */
+int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64_t clip_id_base,
+                     float* x0_out_dev, float* dump_dev, int32_t use_graph, void* stream);
+
+/* R trunk: refine = x_in + head(encoder(...)).  sample_pose_repr_dev, out_dev: (B, T, input_dim) f32;
+ * h2o_dist_dev: (B, T, h2o_dim) f32. */
+int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
+                void* stream);
+
+/* Introspection for bench / profiles: name + grid of the kernels one denoiser step launches. */
+int tamf_step_kernel_count(const tamf_ctx* ctx);
+
+/* ---- kernel-level test hooks (used by tests/ only; same kernels the step uses) ------------------- */
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, optional activation (0 none, 1 silu, 2 gelu_erf); all f32 device buffers;
+ * operands are converted to `precision` on the fly by the library's own pack kernels. */
+int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                   const float* bias_dev, int32_t act, float* c_dev, void* stream);
+/* y = LayerNorm(resid + A.W^T + bias) * gamma + beta with N == latent width (128/256/512). */
+int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                      const float* bias_dev, const float* resid_dev, const float* gamma_dev,
+                      const float* beta_dev, float* y_dev, void* stream);
+/* out[b,s,h*hd+e] = softmax(q k^T / sqrt(hd)) v per (b,h); qkv_dev: (B, S, 3*H*hd) f32 packed [q|k|v]. */
+int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
+                        float* out_dev, void* stream);
+/* Philox normal draws exactly as the sampling loop generates them: out (B, n_feat, 1, T). */
+int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
+                     float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMF_HIP_H */

@@ -1,0 +1,187 @@
+// Device-side building blocks shared by the gfx950 kernels: MFMA operand traits for the three arithmetic
+// modes, LDS swizzles, bf16 split helpers, wave reductions, Philox noise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define TAMF_DEV __device__ __forceinline__
+
+TAMF_DEV uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
+TAMF_DEV float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+TAMF_DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
+TAMF_DEV int as_i(float v) { return __builtin_bit_cast(int, v); }
+
+// torch.nan_to_num defaults: NaN -> 0, +-inf -> +-FLT_MAX  (interaction_segment_mdm.py:158,166,173)
+TAMF_DEV float nan_to_num(float v) {
+  if (v != v) return 0.0f;
+  if (v == __builtin_inff()) return 3.4028234663852886e38f;
+  if (v == -__builtin_inff()) return -3.4028234663852886e38f;
+  return v;
+}
+TAMF_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+TAMF_DEV float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+TAMF_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------
+// LDS swizzles: a tile row of ROWB bytes is a sequence of 16-byte chunks; an MFMA fragment read takes, for
+// lane (r = lane & 15, g = lane >> 4), chunk 4*kc + g of row r.  XOR-ing the chunk index with a function of
+// the row makes the ds_read_b128 lane groups conflict-free (tools/lds_bank_sim.py).
+// ---------------------------------------------------------------------------------------------
+template <int ROWB>
+TAMF_DEV int swz_chunk(int row) {
+  if constexpr (ROWB == 64) {
+    return (4 - ((row >> 2) & 3)) & 3;
+  } else if constexpr (ROWB == 128) {
+    return (row >> 1) & 7;
+  } else {
+    return row & 15;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand traits.  A "fragment" is 16 bytes per lane per plane; one mma() consumes one 64-byte K-chunk of a
+// 16-row A tile and a 16-row B tile:  acc(16x16) += Arows . Brows^T, C layout row = 4*(lane>>4)+reg (A row),
+// col = lane & 15 (B row).
+// ---------------------------------------------------------------------------------------------
+struct OpF32 {
+  typedef float elem_t;
+  static constexpr int EB = 4;  // bytes per element
+  static constexpr int NP = 1;  // operand planes
+  static constexpr int PREC = 0;
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[1], const int4 (&b)[1]) {
+    // the 4 floats of a fragment are 4 K-steps of v_mfma_f32_16x16x4_f32 (lane group g supplies k = g);
+    // A and B use the same permuted K order, so the products pair up exactly.
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].x), as_f(b[0].x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].y), as_f(b[0].y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].z), as_f(b[0].z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].w), as_f(b[0].w), acc, 0, 0, 0);
+  }
+  template <int N>
+  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
+    (void)plane_stride;
+    float* p = base + idx;
+    if constexpr (N == 8) {
+      *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if constexpr (N == 4) {
+      *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      *(float2*)p = make_float2(v[0], v[1]);
+    }
+  }
+};
+
+struct OpBF16 {
+  typedef uint16_t elem_t;
+  static constexpr int EB = 2;
+  static constexpr int NP = 1;
+  static constexpr int PREC = 1;
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[1], const int4 (&b)[1]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]),
+                                                  acc, 0, 0, 0);
+  }
+  template <int N>
+  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
+    (void)plane_stride;
+    uint32_t w[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) w[i] = f2bf(v[2 * i]) | (f2bf(v[2 * i + 1]) << 16);
+    elem_t* p = base + idx;
+    if constexpr (N == 8) {
+      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if constexpr (N == 4) {
+      *(uint2*)p = make_uint2(w[0], w[1]);
+    } else {
+      *(uint32_t*)p = w[0];
+    }
+  }
+};
+
+struct OpBF16X3 {
+  typedef uint16_t elem_t;
+  static constexpr int EB = 2;
+  static constexpr int NP = 2;  // plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi)
+  static constexpr int PREC = 2;
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), al = __builtin_bit_cast(bf16x8, a[1]);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b[0]), bl = __builtin_bit_cast(bf16x8, b[1]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  template <int N>
+  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
+    uint32_t hi[N], w[N / 2];
+    float lo[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      hi[i] = f2bf(v[i]);
+      lo[i] = v[i] - bf2f(hi[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) w[i] = hi[2 * i] | (hi[2 * i + 1] << 16);
+    elem_t* p = base + idx;
+    if constexpr (N == 8) {
+      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if constexpr (N == 4) {
+      *(uint2*)p = make_uint2(w[0], w[1]);
+    } else {
+      *(uint32_t*)p = w[0];
+    }
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) w[i] = f2bf(lo[2 * i]) | (f2bf(lo[2 * i + 1]) << 16);
+    p = base + plane_stride + idx;
+    if constexpr (N == 8) {
+      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if constexpr (N == 4) {
+      *(uint2*)p = make_uint2(w[0], w[1]);
+    } else {
+      *(uint32_t*)p = w[0];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+TAMF_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller (restated in oracle/mdm_oracle.py:philox_normal)
+// ---------------------------------------------------------------------------------------------
+TAMF_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                            uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)c0 * 0xD2511F53u;
+    const uint64_t p1 = (uint64_t)c2 * 0xCD9E8D57u;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// element e of clip `clip` at draw `draw`: counter (e >> 2, draw, clip_lo, clip_hi), key (seed_lo, seed_hi)
+TAMF_DEV float philox_normal_elem(uint64_t seed, int64_t clip, uint32_t draw, uint32_t e) {
+  uint32_t r[4];
+  philox4x32_10(e >> 2, draw, (uint32_t)((uint64_t)clip & 0xFFFFFFFFu), (uint32_t)((uint64_t)clip >> 32),
+                (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), r);
+  const int pair = (e >> 1) & 1;
+  const float u0 = __fadd_rn(__fmul_rn((float)r[2 * pair], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
+  const float u1 = __fadd_rn(__fmul_rn((float)r[2 * pair + 1], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
+  const float rad = sqrtf(__fmul_rn(-2.0f, logf(u0)));
+  const float ang = __fmul_rn(6.283185307179586f, u1);
+  return (e & 1) ? __fmul_rn(rad, sinf(ang)) : __fmul_rn(rad, cosf(ang));
+}

@@ -1,0 +1,472 @@
+// LDS-staged MFMA GEMM for gfx950 with row-wise fused epilogues.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A: [NP][M][lda] operand planes, W: [NP][N][ldw] operand planes
+//
+// One 256-thread workgroup (4 waves, WGM x WGN) owns a BM x BN tile.  K is walked in tiles of BKB bytes
+// per row; tile k+1 is fetched global->registers while tile k is multiplied out of LDS (double-buffered,
+// one barrier per K tile).  LDS rows are XOR-swizzled so that both the 16-byte staging stores and the
+// ds_read_b128 fragment reads are bank-conflict free (tools/lds_bank_sim.py).  After the K loop the fp32
+// accumulators are parked in an LDS C tile (aliasing the staging buffers) and the epilogue walks it row-wise
+// with 16-byte global accesses: bias / activation / residual + LayerNorm / V-transpose / DDPM update are all
+// fused here, so every GEMM output is written to HBM exactly once, already in the operand format (bf16,
+// split bf16 or f32) of the kernel that consumes it.
+#pragma once
+#include "tamf_device.h"
+
+template <class Op>
+struct GemmArgs {
+  const typename Op::elem_t* A;
+  long a_ps;  // plane stride (elements)
+  int lda;
+  const typename Op::elem_t* W;
+  long w_ps;
+  int ldw;
+  int M, N, K;
+};
+
+template <class Op, int BM, int BN, int BKB>
+struct GemmSmem {
+  static constexpr int LDC = BN + 4;
+  static constexpr int STAGE = Op::NP * (BM + BN) * BKB;
+  static constexpr int CBYTES = BM * LDC * 4;
+  static constexpr int BYTES = (2 * STAGE > CBYTES) ? 2 * STAGE : CBYTES;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  Each provides run<BM,BN,NT>(Ct, LDC, m0, n0, M, tid): Ct is the fp32 C tile in LDS.
+// ------------------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+
+TAMF_DEV void ct_load8(const float* Ct, int LDC, int row, int col, float (&v)[8]) {
+  const float4 a = *(const float4*)(Ct + row * LDC + col);
+  const float4 b = *(const float4*)(Ct + row * LDC + col + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+TAMF_DEV void g_load8(const float* p, float (&v)[8]) {
+  const float4 a = *(const float4*)p;
+  const float4 b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// out = act(C + bias[n] + rowadd[m][n]) stored as an operand (FFN1+GELU, input_merge.0+SiLU, hoisted GEMMs)
+template <class OutOp>
+struct EpiBiasAct {
+  const float* bias;    // [N] or null
+  const float* rowadd;  // [M][ld_rowadd] or null
+  int ld_rowadd;
+  typename OutOp::elem_t* out;
+  long out_ps;
+  int ldo;
+  int act;
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    constexpr int VPR = BN / 8;
+    for (int it = tid; it < BM * VPR; it += NT) {
+      const int row = it / VPR, col = (it % VPR) * 8;
+      const int gr = m0 + row, gn = n0 + col;
+      if (gr >= M) continue;
+      float v[8];
+      ct_load8(Ct, LDC, row, col, v);
+      if (bias) {
+        float b[8];
+        g_load8(bias + gn, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+      }
+      if (rowadd) {
+        float b[8];
+        g_load8(rowadd + (long)gr * ld_rowadd + gn, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+      }
+      if (act == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
+      } else if (act == ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+      }
+      OutOp::template store<8>(out, out_ps, (long)gr * ldo + gn, v);
+    }
+  }
+};
+
+// in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed
+// per (clip, head): Vt[((b*H + h)*hd + e)][s], keys contiguous (what the P.V MFMA wants as its K axis).
+template <class Op>
+struct EpiQKV {
+  const float* bias;  // [3d]
+  typename Op::elem_t* qk;
+  long qk_ps;
+  typename Op::elem_t* vt;
+  long vt_ps;
+  int d, H, hd, Sp, Skp;
+  float qscale;
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    if (n0 < 2 * d) {
+      constexpr int VPR = BN / 8;
+      const float sc = (n0 < d) ? qscale : 1.0f;
+      for (int it = tid; it < BM * VPR; it += NT) {
+        const int row = it / VPR, col = (it % VPR) * 8;
+        const int gr = m0 + row, gn = n0 + col;
+        if (gr >= M) continue;
+        float v[8], b[8];
+        ct_load8(Ct, LDC, row, col, v);
+        g_load8(bias + gn, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
+        Op::template store<8>(qk, qk_ps, (long)gr * (2 * d) + gn, v);
+      }
+    } else {
+      for (int it = tid; it < (BM / 8) * BN; it += NT) {
+        const int col = it % BN, rg = it / BN;
+        const int gr0 = m0 + rg * 8;
+        if (gr0 >= M) continue;
+        const int eg = n0 - 2 * d + col;
+        const int h = eg / hd, e = eg % hd;
+        const int b = gr0 / Sp, s0 = gr0 % Sp;
+        const float bb = bias[n0 + col];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Ct[(rg * 8 + j) * LDC + col] + bb;
+        Op::template store<8>(vt, vt_ps, ((long)(b * H + h) * hd + e) * Skp + s0, v);
+      }
+    }
+  }
+};
+
+// input_merge.2 (+ bias, nan_to_num, + positional row) scattered into the token rows of the sequence;
+// also builds the timestep-embedding table.  GEMM row r = (b, tau) with b = r / Tdiv, tau = r % Tdiv goes
+// to output row b*Sp + P + tau and gets pe[tau * pe_stride + n] added.
+template <class Op>
+struct EpiSeqRows {
+  const float* bias;
+  const float* pe;
+  int pe_stride;
+  float* xout;  // [rows][d] fp32 or null
+  typename Op::elem_t* xop;  // operand planes or null
+  long xop_ps;
+  int d, Tdiv, Sp, P;
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    constexpr int VPR = BN / 8;
+    for (int it = tid; it < BM * VPR; it += NT) {
+      const int row = it / VPR, col = (it % VPR) * 8;
+      const int gr = m0 + row, gn = n0 + col;
+      if (gr >= M) continue;
+      const int b = gr / Tdiv, tau = gr % Tdiv;
+      const long orow = (long)b * Sp + P + tau;
+      float v[8], bi[8], pv[8];
+      ct_load8(Ct, LDC, row, col, v);
+      g_load8(bias + gn, bi);
+      g_load8(pe + (long)tau * pe_stride + gn, pv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
+      if (xout) g_store8(xout + orow * d + gn, v);
+      if (xop) Op::template store<8>(xop, xop_ps, orow * d + gn, v);
+    }
+  }
+};
+
+// y = LayerNorm(resid + C + bias) * gamma + beta over the full row (BN == N == d); one wave per row.
+template <class Op>
+struct EpiLN {
+  const float* bias;
+  const float* resid;  // [M][d]
+  const float* gamma;
+  const float* beta;
+  float* xout;  // [M][d] (may alias resid: every row is read and written by the same wave)
+  typename Op::elem_t* xop;
+  long xop_ps;
+  float eps;
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    (void)n0;
+    constexpr int VPL = BN / 64;
+    constexpr int NW = NT / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c0 = lane * VPL;
+    float bi[VPL], ga[VPL], be[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      bi[j] = bias[c0 + j];
+      ga[j] = gamma[c0 + j];
+      be[j] = beta[c0 + j];
+    }
+    for (int row = wave; row < BM; row += NW) {
+      const int gr = m0 + row;
+      if (gr >= M) break;
+      float v[VPL];
+      const float* rp = resid + (long)gr * BN + c0;
+      const float* cp = Ct + row * LDC + c0;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        v[j] = (cp[j] + bi[j]) + rp[j];
+        s += v[j];
+      }
+      const float mean = wave_sum(s) * (1.0f / BN);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const float dlt = v[j] - mean;
+        q += dlt * dlt;
+      }
+      const float var = wave_sum(q) * (1.0f / BN);
+      const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * ga[j] + be[j];
+      float* op = xout + (long)gr * BN + c0;
+      if constexpr (VPL == 8) {
+        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else if constexpr (VPL == 4) {
+        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *(float2*)op = make_float2(v[0], v[1]);
+      }
+      Op::template store<VPL>(xop, xop_ps, (long)gr * BN + c0, v);
+    }
+  }
+};
+
+// output_process.poseFinal (+ bias, nan_to_num) fused with either the x0 write-out in the reference layout
+// (B, F, 1, T) or the DDPM reverse update of the frame-major sampler state.
+enum { HEAD_X0 = 0, HEAD_DDPM = 1, HEAD_RESIDUAL = 2 };
+template <class Op>
+struct EpiHead {
+  const float* bias;  // [XN] padded
+  int mode;
+  int F, T, Sp, P, XK;  // XK: row stride of the state (F padded)
+  float* x0_out;        // HEAD_X0: (B, F, 1, T); HEAD_RESIDUAL: (B, T, F)
+  const float* x_in;    // HEAD_RESIDUAL: (B, T, F)
+  float* xs;            // HEAD_DDPM: state [B*T][XK]
+  typename Op::elem_t* xs_op;
+  long xs_op_ps;
+  const int* tcur;      // device: current timestep index of every clip (uniform inside the loop)
+  const float* c1;
+  const float* c2;
+  const float* sigma;
+  int n_steps;
+  const float* noise;   // (n_steps+1, B, F, 1, T) or null -> Philox
+  long noise_draw_stride;
+  unsigned long long seed;
+  long long clip_base;
+  float* dump;          // (n_steps, B, F, 1, T) or null
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    constexpr int VPR = BN / 8;
+    for (int it = tid; it < BM * VPR; it += NT) {
+      const int row = it / VPR, col = (it % VPR) * 8;
+      const int gr = m0 + row, gn = n0 + col;
+      if (gr >= M) continue;
+      const int b = gr / Sp, s = gr % Sp;
+      if (s < P || s >= P + T) continue;
+      const int tau = s - P;
+      float v[8], bi[8];
+      ct_load8(Ct, LDC, row, col, v);
+      g_load8(bias + gn, bi);
+      if (mode == HEAD_X0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = gn + j;
+          if (c < F) x0_out[((long)b * F + c) * T + tau] = nan_to_num(v[j] + bi[j]);
+        }
+      } else if (mode == HEAD_RESIDUAL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = gn + j;
+          const long o = ((long)b * T + tau) * F + c;
+          if (c < F) x0_out[o] = nan_to_num(x_in[o] + (v[j] + bi[j]));
+        }
+      } else {
+        const int ti = tcur[0];
+        const float k1 = c1[ti], k2 = c2[ti], sg = sigma[ti];
+        const unsigned draw = (unsigned)(n_steps - ti);
+        const long srow = ((long)b * T + tau) * XK;
+        float xt[8], xn[8];
+        g_load8(xs + srow + gn, xt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = gn + j;
+          if (c < F) {
+            const float x0 = nan_to_num(v[j] + bi[j]);
+            // mean = coef1*x0 + coef2*x_t ; sample = mean + [t!=0]*sigma*eps  (gaussian_diffusion.py:221-224,459)
+            float r = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xt[j]));
+            if (ti != 0) {
+              float e;
+              if (noise) e = noise[(long)draw * noise_draw_stride + ((long)b * F + c) * T + tau];
+              else e = philox_normal_elem(seed, clip_base + b, draw, (unsigned)(c * T + tau));
+              r = __fadd_rn(r, __fmul_rn(sg, e));
+            }
+            xn[j] = r;
+            if (dump) dump[(long)(draw - 1) * noise_draw_stride + ((long)b * F + c) * T + tau] = r;
+          } else {
+            xn[j] = 0.f;
+          }
+        }
+        g_store8(xs + srow + gn, xn);
+        Op::template store<8>(xs_op, xs_op_ps, srow + gn, xn);
+      }
+    }
+  }
+};
+
+// plain fp32 store (test hook)
+struct EpiStoreF32 {
+  const float* bias;
+  float* out;
+  int ldo;
+  int act;
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    constexpr int VPR = BN / 8;
+    for (int it = tid; it < BM * VPR; it += NT) {
+      const int row = it / VPR, col = (it % VPR) * 8;
+      const int gr = m0 + row, gn = n0 + col;
+      if (gr >= M) continue;
+      float v[8];
+      ct_load8(Ct, LDC, row, col, v);
+      if (bias) {
+        float b[8];
+        g_load8(bias + gn, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+      }
+      if (act == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
+      } else if (act == ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+      }
+      g_store8(out + (long)gr * ldo + gn, v);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The kernel
+// ------------------------------------------------------------------------------------------------
+template <class Op, int BM, int BN, int WGM, int WGN, int BKB, class Epi>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> ga, const Epi epi) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int NP = Op::NP;
+  constexpr int CPR = BKB / 16;  // 16-byte chunks per tile row
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int A_CH = BM * CPR * NP, W_CH = BN * CPR * NP;
+  constexpr int A_PT = A_CH / NT, W_PT = W_CH / NT;
+  static_assert(A_CH % NT == 0 && W_CH % NT == 0, "staging must divide evenly");
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
+  typedef GemmSmem<Op, BM, BN, BKB> SM;
+  constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int M = ga.M;
+  const int KT = (ga.K * Op::EB) / BKB;
+
+  // per-thread staging slots: global byte offsets (without the k-tile term) and LDS byte offsets
+  long a_goff[A_PT], w_goff[W_PT];
+  int a_soff[A_PT], w_soff[W_PT];
+#pragma unroll
+  for (int i = 0; i < A_PT; ++i) {
+    const int q = tid + i * NT;
+    const int p = q / (BM * CPR), rem = q % (BM * CPR);
+    const int row = rem / CPR, ch = rem % CPR;
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    a_goff[i] = ((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB + ch * 16;
+    a_soff[i] = p * A_BYTES + row * BKB + ((ch ^ swz_chunk<BKB>(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int q = tid + i * NT;
+    const int p = q / (BN * CPR), rem = q % (BN * CPR);
+    const int row = rem / CPR, ch = rem % CPR;
+    w_goff[i] = ((long)p * ga.w_ps + (long)(n0 + row) * ga.ldw) * Op::EB + ch * 16;
+    w_soff[i] = NP * A_BYTES + p * W_BYTES + row * BKB + ((ch ^ swz_chunk<BKB>(row)) << 4);
+  }
+  const char* Ab = (const char*)ga.A;
+  const char* Wb = (const char*)ga.W;
+
+  int4 ra[A_PT], rw[W_PT];
+  auto gload = [&](int kt) {
+    const long ko = (long)kt * BKB;
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) ra[i] = *(const int4*)(Ab + a_goff[i] + ko);
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) rw[i] = *(const int4*)(Wb + w_goff[i] + ko);
+  };
+  auto swrite = [&](int s) {
+    char* base = smem + s * SM::STAGE;
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) *(int4*)(base + a_soff[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) *(int4*)(base + w_soff[i]) = rw[i];
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = swz_chunk<BKB>(lr);  // tile rows are multiples of 16 apart: the swizzle depends on lr only
+  const int a_frag = (wm0 + lr) * BKB;
+  const int w_frag = NP * A_BYTES + (wn0 + lr) * BKB;
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const char* base = smem + cur * SM::STAGE;
+#pragma unroll
+    for (int kc = 0; kc < BKB / 64; ++kc) {
+      const int coff = (((kc * 4 + g) ^ sw) << 4);
+      int4 af[MI][NP];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) af[mi][p] = *(const int4*)(base + p * A_BYTES + a_frag + mi * 16 * BKB + coff);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int4 wf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wf[p] = *(const int4*)(base + p * W_BYTES + w_frag + ni * 16 * BKB + coff);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf, af[mi]);  // D rows = n (4g+reg), cols = m (lr)
+      }
+    }
+    if (kt + 1 < KT) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // park the accumulators in the LDS C tile: lane (g, lr) holds C[m = lr][n = 4g .. 4g+3] of each 16x16 tile
+  float* Ct = (float*)smem;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const f32x4 v = acc[mi][ni];
+      *(float4*)(Ct + (wm0 + mi * 16 + lr) * SM::LDC + wn0 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  __syncthreads();
+  epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
+}

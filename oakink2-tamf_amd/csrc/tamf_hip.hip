@@ -1,0 +1,929 @@
+// libtamf_hip.so - host side of the C-ABI declared in include/tamf_hip.h: context, weight repacking,
+// step-invariant conditioning precompute, the per-step kernel sequence and its hipGraph replay loop.
+// gfx950 (MI355X) only.
+#include "../../include/tamf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "tamf_attn.h"
+#include "tamf_gemm.h"
+#include "tamf_misc.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static std::string g_noctx_err;
+
+struct OperandBuf {
+  void* p = nullptr;
+  long ps = 0;  // plane stride in elements
+};
+
+struct LayerW {
+  OperandBuf Win, Wout, W1, W2;
+  float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+};
+
+struct GraphKey {
+  int B = -1, T = -1, n_steps = -1;
+  const void* noise = nullptr;
+  void* dump = nullptr;
+  uint64_t seed = 0;
+  int64_t clip_base = 0;
+  bool operator==(const GraphKey& o) const {
+    return B == o.B && T == o.T && n_steps == o.n_steps && noise == o.noise && dump == o.dump && seed == o.seed &&
+           clip_base == o.clip_base;
+  }
+};
+
+struct tamf_ctx {
+  tamf_arch arch{};
+  int prec = 0, device = 0, Bmax = 0, Tmax = 0;
+  int d = 0, ff = 0, L = 0, H = 0, hd = 0, P = 0, F = 0, has_t = 0;
+  int XK = 0;   // padded K of the fused input GEMM
+  int XN = 128; // padded N of the output head
+  int NP = 1, EB = 4;
+  std::string err;
+  std::vector<void*> allocs;
+  std::map<std::string, std::vector<float>> raw;
+  std::map<std::string, std::vector<int64_t>> raw_shape;
+  bool finalized = false, cond_set = false;
+  int n_t = 0;  // rows of the timestep table
+  // schedule
+  int n_steps = 0;
+  std::vector<float> h_c1, h_c2, h_sigma;
+  float *c1 = nullptr, *c2 = nullptr, *sigma = nullptr;
+  // weights
+  std::vector<LayerW> layers;
+  OperandBuf Wfused, Wm2, Wf;
+  float *bm2 = nullptr, *bf = nullptr, *cbias = nullptr;
+  float* pe = nullptr;    // [5000][d]
+  float* temb = nullptr;  // [n_t][d]
+  OperandBuf Wm1b_f32, Wt1_f32, Wt2_f32;
+  float *bt1 = nullptr, *bt2 = nullptr;
+  float *Wtxt = nullptr, *btxt = nullptr, *Wshape = nullptr, *bshape = nullptr, *Wobj = nullptr, *bobj = nullptr;
+  float *Wq = nullptr, *bq = nullptr, *rh = nullptr, *lh = nullptr;
+  // activations
+  int B = 0, T = 0, S = 0, Sp = 0, Skp = 0, M = 0;
+  long Mmax = 0;
+  float *xs = nullptr, *cobj = nullptr, *X = nullptr, *pstatic = nullptr, *etmp = nullptr, *meanbuf = nullptr,
+        *objfeat = nullptr;
+  OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
+  int* tcur = nullptr;
+  unsigned char* side_dev = nullptr;
+  // graph
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  GraphKey graph_key;
+  int step_kernels = 0;
+};
+
+static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  else g_noctx_err = msg;
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                                         \
+  do {                                                                                                            \
+    hipError_t e_ = (call);                                                                                       \
+    if (e_ != hipSuccess)                                                                                         \
+      return fail(ctx, TAMF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" +  \
+                                         std::to_string(__LINE__) + ")");                                        \
+  } while (0)
+#define TRY(expr)           \
+  do {                      \
+    int rc_ = (expr);       \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int dev_alloc(tamf_ctx* ctx, void** p, size_t bytes, bool zero = false) {
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return fail(ctx, TAMF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  ctx->allocs.push_back(*p);
+  if (zero) HIPCHK(ctx, hipMemset(*p, 0, bytes));
+  return 0;
+}
+template <class T>
+static int dev_upload(tamf_ctx* ctx, T** p, const T* host, size_t n) {
+  TRY(dev_alloc(ctx, (void**)p, n * sizeof(T)));
+  HIPCHK(ctx, hipMemcpy(*p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// host float -> bf16 (round to nearest even; NaN kept quiet)
+static inline uint16_t h_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float h_bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// upload host fp32 [N][K] as operand planes [NP][N][ldk] in precision `prec` (cols >= K zero)
+static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out) {
+  const size_t n = (size_t)N * ldk;
+  out->ps = (long)n;
+  if (prec == TAMF_PREC_F32) {
+    std::vector<float> h(n, 0.f);
+    for (int r = 0; r < N; ++r) memcpy(&h[(size_t)r * ldk], &w[(size_t)r * K], (size_t)K * 4);
+    return dev_upload(ctx, (float**)&out->p, h.data(), n);
+  }
+  const int np = prec == TAMF_PREC_BF16X3 ? 2 : 1;
+  std::vector<uint16_t> h(n * np, 0);
+  for (int r = 0; r < N; ++r)
+    for (int k = 0; k < K; ++k) {
+      const float v = w[(size_t)r * K + k];
+      const uint16_t hi = h_f2bf(v);
+      h[(size_t)r * ldk + k] = hi;
+      if (np == 2) h[n + (size_t)r * ldk + k] = h_f2bf(v - h_bf2f(hi));
+    }
+  return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * np);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel launchers
+// ------------------------------------------------------------------------------------------------
+template <class Op, int BM, int BN, int BKB, class Epi>
+struct GemmLaunch {
+  static constexpr int SMEM = GemmSmem<Op, BM, BN, BKB>::BYTES;
+  static hipError_t prepare() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) done = true;
+    return e;
+  }
+  static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+    hipError_t e = prepare();
+    if (e != hipSuccess) return e;
+    if ((ga.K * Op::EB) % BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
+    dim3 grid(ga.N / BN, (ga.M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>), grid, dim3(256), SMEM, st, ga, epi);
+    return hipGetLastError();
+  }
+};
+template <class Op>
+struct TileCfg {
+  static constexpr int BKB = Op::NP == 2 ? 64 : 128;
+};
+template <class Op, class Epi>
+static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+  return GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, Epi>::launch(ga, epi, st);
+}
+template <class Op>
+static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st) {
+  switch (ga.N) {
+    case 128: return GemmLaunch<Op, 64, 128, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
+    case 256: return GemmLaunch<Op, 64, 256, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
+    case 512: return GemmLaunch<Op, 64, 512, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <class Op>
+static hipError_t prepare_all() {
+  hipError_t e;
+  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiHead<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 256, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 512, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+template <class Op>
+static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
+  const int nqt = (aa.Sp + 15) / 16;
+  const int chunks = (nqt + 7) / 8;
+  const int nw = (nqt + chunks - 1) / chunks;
+  dim3 grid(chunks, B * aa.H);
+  constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;
+  if (hd == 64) {
+    hipLaunchKernelGGL((attn_kernel<Op, 64>), grid, dim3(nw * 64), smem64, st, aa);
+  } else if (hd == 128) {
+    hipLaunchKernelGGL((attn_kernel<Op, 128>), grid, dim3(nw * 64), smem128, st, aa);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+static inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* tamf_last_error(const tamf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_noctx_err.c_str(); }
+
+static int alloc_operand(tamf_ctx* ctx, OperandBuf* ob, long elems, bool zero = false) {
+  ob->ps = elems;
+  return dev_alloc(ctx, &ob->p, (size_t)elems * ctx->NP * ctx->EB, zero);
+}
+
+extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames, int32_t precision,
+                               int32_t device, tamf_ctx** out) {
+  if (!arch || !out) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const int d = arch->latent_dim;
+  if (!(d == 128 || d == 256 || d == 512)) return fail(nullptr, TAMF_ERR_INVALID, "latent_dim must be 128, 256 or 512");
+  if (arch->num_heads <= 0 || d % arch->num_heads) return fail(nullptr, TAMF_ERR_INVALID, "bad num_heads");
+  const int hd = d / arch->num_heads;
+  if (!(hd == 64 || hd == 128)) return fail(nullptr, TAMF_ERR_INVALID, "head dim (latent_dim/num_heads) must be 64 or 128");
+  if (arch->ff_size <= 0 || arch->ff_size % 128) return fail(nullptr, TAMF_ERR_INVALID, "ff_size must be a multiple of 128");
+  if (arch->num_layers <= 0 || arch->num_layers > 64) return fail(nullptr, TAMF_ERR_INVALID, "bad num_layers");
+  if (arch->input_dim <= 0 || arch->input_dim > 128) return fail(nullptr, TAMF_ERR_INVALID, "input_dim must be in [1,128]");
+  if (precision < 0 || precision > 2) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  if (arch->kind != TAMF_KIND_G && arch->kind != TAMF_KIND_R) return fail(nullptr, TAMF_ERR_INVALID, "unknown model kind");
+  if (max_batch <= 0 || max_frames <= 0 || max_frames > 4990) return fail(nullptr, TAMF_ERR_INVALID, "bad max_batch/max_frames");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, TAMF_ERR_HIP, "no HIP device visible: libtamf_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, TAMF_ERR_INVALID, "device index out of range");
+
+  tamf_ctx* ctx = new tamf_ctx();
+  ctx->arch = *arch;
+  ctx->prec = precision;
+  ctx->device = device;
+  ctx->Bmax = max_batch;
+  ctx->Tmax = max_frames;
+  ctx->d = d;
+  ctx->ff = arch->ff_size;
+  ctx->L = arch->num_layers;
+  ctx->H = arch->num_heads;
+  ctx->hd = hd;
+  ctx->F = arch->input_dim;
+  ctx->has_t = arch->kind == TAMF_KIND_G ? 1 : 0;
+  ctx->P = arch->kind == TAMF_KIND_G ? 5 : 3;
+  ctx->XK = arch->kind == TAMF_KIND_G ? 128 : round_up(arch->input_dim + arch->h2o_dim, 64);
+  ctx->NP = precision == TAMF_PREC_BF16X3 ? 2 : 1;
+  ctx->EB = precision == TAMF_PREC_F32 ? 4 : 2;
+  ctx->layers.resize(ctx->L);
+
+  auto bail = [&](int rc) {
+    std::string e = ctx->err;
+    tamf_ctx_destroy(ctx);
+    g_noctx_err = e;
+    return rc;
+  };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(ctx, TAMF_ERR_HIP, "hipSetDevice failed"));
+  hipError_t pe = prepare_all<OpF32>();
+  if (pe == hipSuccess && precision == TAMF_PREC_BF16) pe = prepare_all<OpBF16>();
+  if (pe == hipSuccess && precision == TAMF_PREC_BF16X3) pe = prepare_all<OpBF16X3>();
+  if (pe != hipSuccess)
+    return bail(fail(ctx, TAMF_ERR_HIP, std::string("kernel attribute setup failed: ") + hipGetErrorString(pe)));
+  if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(ctx, TAMF_ERR_HIP, "hipStreamCreate failed"));
+
+  const int Smax = max_frames + ctx->P, Spmax = round_up(Smax, 8), Skpmax = round_up(Smax, 32);
+  const long BT = (long)max_batch * max_frames;
+  const long Mmax = (long)max_batch * Spmax;
+  ctx->Mmax = Mmax;
+  int rc = 0;
+  auto A = [&](int r) { if (rc == 0) rc = r; };
+  A(dev_alloc(ctx, (void**)&ctx->xs, BT * ctx->XK * 4, true));
+  A(alloc_operand(ctx, &ctx->xs_op, BT * ctx->XK, true));
+  A(dev_alloc(ctx, (void**)&ctx->cobj, BT * d * 4));
+  A(alloc_operand(ctx, &ctx->h1_op, BT * d));
+  A(dev_alloc(ctx, (void**)&ctx->X, Mmax * d * 4, true));
+  A(alloc_operand(ctx, &ctx->X_op, Mmax * d, true));
+  A(alloc_operand(ctx, &ctx->QK_op, Mmax * 2 * d, true));
+  A(alloc_operand(ctx, &ctx->Vt_op, (long)max_batch * d * Skpmax, true));
+  A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
+  A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
+  A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
+  const long meansz = std::max<long>((long)max_batch * std::max(arch->obj_embed_dim, arch->hand_shape_dim),
+                                     BT * arch->obj_input_dim);
+  A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
+  A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
+  A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
+  if (rc) return bail(rc);
+  *out = ctx;
+  return 0;
+}
+
+extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+  if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static std::map<std::string, std::vector<int64_t>> expected_shapes(const tamf_ctx* c) {
+  std::map<std::string, std::vector<int64_t>> m;
+  const int64_t d = c->d, ff = c->ff;
+  auto lin = [&](const std::string& n, int64_t o, int64_t i) {
+    m[n + ".weight"] = {o, i};
+    m[n + ".bias"] = {o};
+  };
+  m["hand_side_process.rh_embed"] = {d};
+  m["hand_side_process.lh_embed"] = {d};
+  lin("hand_shape_process.shape_embed", d, c->arch.hand_shape_dim);
+  lin("obj_embed_process.embedding", d, c->arch.obj_embed_dim);
+  lin("input_process.poseEmbedding", d, c->arch.input_dim);
+  lin("obj_input_process.poseEmbedding", d, c->arch.obj_input_dim);
+  if (c->arch.kind == TAMF_KIND_R) {
+    lin("h2o_dist_input_process.poseEmbedding", d, c->arch.h2o_dim);
+    lin("input_merge.0", d, 3 * d);
+  } else {
+    lin("input_merge.0", d, 2 * d);
+    lin("embed_timestep.time_embed.0", d, d);
+    lin("embed_timestep.time_embed.2", d, d);
+    lin("embed_text", d, c->arch.clip_dim);
+  }
+  lin("input_merge.2", d, d);
+  m["sequence_pos_encoder.pe"] = {5000, 1, d};
+  for (int l = 0; l < c->L; ++l) {
+    const std::string p = "seqTransEncoder.layers." + std::to_string(l);
+    m[p + ".self_attn.in_proj_weight"] = {3 * d, d};
+    m[p + ".self_attn.in_proj_bias"] = {3 * d};
+    lin(p + ".self_attn.out_proj", d, d);
+    lin(p + ".linear1", ff, d);
+    lin(p + ".linear2", d, ff);
+    m[p + ".norm1.weight"] = {d};
+    m[p + ".norm1.bias"] = {d};
+    m[p + ".norm2.weight"] = {d};
+    m[p + ".norm2.bias"] = {d};
+  }
+  lin("output_process.poseFinal", c->arch.input_dim, d);
+  return m;
+}
+
+extern "C" int tamf_load_weight(tamf_ctx* ctx, const char* name, const float* host_data, const int64_t* shape,
+                                int32_t ndim) {
+  if (!ctx || !name || !host_data || !shape || ndim <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  if (ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights already finalised");
+  const auto exp = expected_shapes(ctx);
+  const auto it = exp.find(name);
+  if (it == exp.end()) return 0;  // strict=False: unexpected keys are ignored (e.g. clip_model.*, aliased pe buffer)
+  std::vector<int64_t> shp(shape, shape + ndim);
+  if (shp != it->second) return fail(ctx, TAMF_ERR_INVALID, std::string("shape mismatch for ") + name);
+  int64_t n = 1;
+  for (auto v : shp) n *= v;
+  ctx->raw[name].assign(host_data, host_data + n);
+  ctx->raw_shape[name] = shp;
+  return 0;
+}
+
+template <class Op>
+static OperandBuf ob_cast(const OperandBuf& o) { return o; }
+
+static int upload_f32(tamf_ctx* ctx, const std::string& name, float** p) {
+  const auto& v = ctx->raw.at(name);
+  return dev_upload(ctx, p, v.data(), v.size());
+}
+
+extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream) {
+  if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
+  if (ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights already finalised");
+  if (max_timesteps <= 0 || max_timesteps > 5000) return fail(ctx, TAMF_ERR_INVALID, "max_timesteps must be in [1,5000]");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  for (const auto& kv : expected_shapes(ctx))
+    if (!ctx->raw.count(kv.first)) return fail(ctx, TAMF_ERR_MISSING, "missing checkpoint tensor: " + kv.first);
+  const int d = ctx->d, ff = ctx->ff, F = ctx->F, prec = ctx->prec;
+  auto R = [&](const std::string& n) -> const float* { return ctx->raw.at(n).data(); };
+
+  for (int l = 0; l < ctx->L; ++l) {
+    const std::string p = "seqTransEncoder.layers." + std::to_string(l);
+    LayerW& w = ctx->layers[l];
+    TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win));
+    TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout));
+    TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1));
+    TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2));
+    TRY(upload_f32(ctx, p + ".self_attn.in_proj_bias", &w.b_in));
+    TRY(upload_f32(ctx, p + ".self_attn.out_proj.bias", &w.b_out));
+    TRY(upload_f32(ctx, p + ".linear1.bias", &w.b1));
+    TRY(upload_f32(ctx, p + ".linear2.bias", &w.b2));
+    TRY(upload_f32(ctx, p + ".norm1.weight", &w.g1));
+    TRY(upload_f32(ctx, p + ".norm1.bias", &w.be1));
+    TRY(upload_f32(ctx, p + ".norm2.weight", &w.g2));
+    TRY(upload_f32(ctx, p + ".norm2.bias", &w.be2));
+  }
+  // fused input weight: input_merge.0[:, :d] . poseEmbedding (and, for R, input_merge.0[:, 2d:] . h2o embedding)
+  {
+    const bool isR = ctx->arch.kind == TAMF_KIND_R;
+    const int mk = isR ? 3 * d : 2 * d;
+    const float* Wm1 = R("input_merge.0.weight");
+    const float* bm1 = R("input_merge.0.bias");
+    const float* Wp = R("input_process.poseEmbedding.weight");
+    const float* bp = R("input_process.poseEmbedding.bias");
+    std::vector<float> fused((size_t)d * ctx->XK, 0.f), cb(d), wm1b((size_t)d * d);
+    for (int n = 0; n < d; ++n) {
+      double acc_b = bm1[n];
+      for (int j = 0; j < d; ++j) acc_b += (double)Wm1[(size_t)n * mk + j] * bp[j];
+      for (int k = 0; k < F; ++k) {
+        double a = 0;
+        for (int j = 0; j < d; ++j) a += (double)Wm1[(size_t)n * mk + j] * Wp[(size_t)j * F + k];
+        fused[(size_t)n * ctx->XK + k] = (float)a;
+      }
+      for (int j = 0; j < d; ++j) wm1b[(size_t)n * d + j] = Wm1[(size_t)n * mk + d + j];
+      if (isR) {
+        const int Hd = ctx->arch.h2o_dim;
+        const float* Wh = R("h2o_dist_input_process.poseEmbedding.weight");
+        const float* bh = R("h2o_dist_input_process.poseEmbedding.bias");
+        for (int j = 0; j < d; ++j) acc_b += (double)Wm1[(size_t)n * mk + 2 * d + j] * bh[j];
+        for (int k = 0; k < Hd; ++k) {
+          double a = 0;
+          for (int j = 0; j < d; ++j) a += (double)Wm1[(size_t)n * mk + 2 * d + j] * Wh[(size_t)j * Hd + k];
+          fused[(size_t)n * ctx->XK + F + k] = (float)a;
+        }
+      }
+      cb[n] = (float)acc_b;
+    }
+    TRY(upload_operand(ctx, prec, fused.data(), d, ctx->XK, ctx->XK, &ctx->Wfused));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, wm1b.data(), d, d, d, &ctx->Wm1b_f32));
+    TRY(dev_upload(ctx, &ctx->cbias, cb.data(), cb.size()));
+  }
+  TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2));
+  TRY(upload_f32(ctx, "input_merge.2.bias", &ctx->bm2));
+  {
+    std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f);
+    memcpy(wf.data(), R("output_process.poseFinal.weight"), (size_t)F * d * 4);
+    memcpy(bfp.data(), R("output_process.poseFinal.bias"), (size_t)F * 4);
+    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf));
+    TRY(dev_upload(ctx, &ctx->bf, bfp.data(), bfp.size()));
+  }
+  TRY(upload_f32(ctx, "sequence_pos_encoder.pe", &ctx->pe));
+  TRY(upload_f32(ctx, "hand_shape_process.shape_embed.weight", &ctx->Wshape));
+  TRY(upload_f32(ctx, "hand_shape_process.shape_embed.bias", &ctx->bshape));
+  TRY(upload_f32(ctx, "obj_embed_process.embedding.weight", &ctx->Wobj));
+  TRY(upload_f32(ctx, "obj_embed_process.embedding.bias", &ctx->bobj));
+  TRY(upload_f32(ctx, "obj_input_process.poseEmbedding.weight", &ctx->Wq));
+  TRY(upload_f32(ctx, "obj_input_process.poseEmbedding.bias", &ctx->bq));
+  TRY(upload_f32(ctx, "hand_side_process.rh_embed", &ctx->rh));
+  TRY(upload_f32(ctx, "hand_side_process.lh_embed", &ctx->lh));
+  if (ctx->has_t) {
+    TRY(upload_f32(ctx, "embed_text.weight", &ctx->Wtxt));
+    TRY(upload_f32(ctx, "embed_text.bias", &ctx->btxt));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.0.weight"), d, d, d, &ctx->Wt1_f32));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.2.weight"), d, d, d, &ctx->Wt2_f32));
+    TRY(upload_f32(ctx, "embed_timestep.time_embed.0.bias", &ctx->bt1));
+    TRY(upload_f32(ctx, "embed_timestep.time_embed.2.bias", &ctx->bt2));
+    // timestep-embedding table: temb[t] = nan_to_num(W2 silu(W1 pe[t] + b1) + b2) + pe[0]   (exact fp32 MFMA)
+    ctx->n_t = max_timesteps;
+    float* tmp = nullptr;
+    TRY(dev_alloc(ctx, (void**)&ctx->temb, (size_t)ctx->n_t * d * 4));
+    TRY(dev_alloc(ctx, (void**)&tmp, (size_t)ctx->n_t * d * 4));
+    GemmArgs<OpF32> g1{ctx->pe, 0, d, (const float*)ctx->Wt1_f32.p, 0, d, ctx->n_t, d, d};
+    EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, 0, d, ACT_SILU};
+    HIPCHK(ctx, gemm128<OpF32>(g1, e1, st));
+    GemmArgs<OpF32> g2{tmp, 0, d, (const float*)ctx->Wt2_f32.p, 0, d, ctx->n_t, d, d};
+    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, 0, d, 0x7FFFFFFF, 0, 0};
+    HIPCHK(ctx, gemm128<OpF32>(g2, e2, st));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->raw.clear();
+  ctx->finalized = true;
+  return 0;
+}
+
+extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c1, const double* c2, const double* logvar) {
+  if (!ctx || !c1 || !c2 || !logvar || n_steps <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->h_c1.resize(n_steps);
+  ctx->h_c2.resize(n_steps);
+  ctx->h_sigma.resize(n_steps);
+  for (int i = 0; i < n_steps; ++i) {
+    ctx->h_c1[i] = (float)c1[i];  // float64 -> float32 cast of _extract_into_tensor (gaussian_diffusion.py:1275)
+    ctx->h_c2[i] = (float)c2[i];
+    ctx->h_sigma[i] = expf(0.5f * (float)logvar[i]);  // th.exp(0.5 * log_variance) on float32 (:459)
+  }
+  ctx->n_steps = n_steps;
+  TRY(dev_upload(ctx, &ctx->c1, ctx->h_c1.data(), n_steps));
+  TRY(dev_upload(ctx, &ctx->c2, ctx->h_c2.data(), n_steps));
+  TRY(dev_upload(ctx, &ctx->sigma, ctx->h_sigma.data(), n_steps));
+  ctx->graph_key = GraphKey();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conditioning (step-invariant precompute, always exact fp32)
+// ------------------------------------------------------------------------------------------------
+extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const float* text_emb_dev,
+                             const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
+                             const float* obj_traj_dev, void* stream) {
+  if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
+  if (!ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights not finalised");
+  if (B <= 0 || B > ctx->Bmax || T <= 0 || T > ctx->Tmax || nobj <= 0) return fail(ctx, TAMF_ERR_INVALID, "B/T/nobj out of range");
+  if (!hand_side_host || !shape_dev || !obj_emb_dev || !obj_traj_dev || (ctx->has_t && !text_emb_dev))
+    return fail(ctx, TAMF_ERR_INVALID, "null conditioning tensor");
+  for (int b = 0; b < B; ++b)
+    if (hand_side_host[b] > 1) return fail(ctx, TAMF_ERR_INVALID, "unexpected hand_side: " + std::to_string(hand_side_host[b]));
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int d = ctx->d, P = ctx->P, ht = ctx->has_t, nrows = P - ht;
+  ctx->B = B;
+  ctx->T = T;
+  ctx->S = T + P;
+  ctx->Sp = round_up(ctx->S, 8);
+  ctx->Skp = round_up(ctx->S, 32);
+  ctx->M = B * ctx->Sp;
+  ctx->cond_set = false;
+  ctx->graph_key = GraphKey();
+  int j = 0;
+  if (ht) {
+    hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, text_emb_dev, ctx->Wtxt, ctx->btxt,
+                       ctx->etmp, (long)B, d, ctx->arch.clip_dim);
+    hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d,
+                       nrows, j, ht + j);
+    ++j;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->side_dev, hand_side_host, B, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(hand_side_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->side_dev, ctx->rh, ctx->lh, ctx->etmp, B, d);
+  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
+                     j, ht + j);
+  ++j;
+  const int sd = ctx->arch.hand_shape_dim;
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * sd), dim3(256), 0, st, shape_dev, ctx->meanbuf, B, T, sd);
+  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wshape, ctx->bshape,
+                     ctx->etmp, (long)B, d, sd);
+  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
+                     j, ht + j);
+  ++j;
+  const int od = ctx->arch.obj_embed_dim;
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * od), dim3(256), 0, st, obj_emb_dev, ctx->meanbuf, B, nobj, od);
+  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wobj, ctx->bobj,
+                     ctx->etmp, (long)B, d, od);
+  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
+                     j, ht + j);
+  // object half of input_merge.0, hoisted: cobj[b,tau,:] = W_m1[:, d:2d] (W_q mean_o traj + b_q) + fused bias
+  const int qd = ctx->arch.obj_input_dim;
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd);
+  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * T * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wq, ctx->bq,
+                     ctx->objfeat, (long)B * T, d, qd);
+  GemmArgs<OpF32> ga{ctx->objfeat, 0, d, (const float*)ctx->Wm1b_f32.p, 0, d, B * T, d, d};
+  EpiBiasAct<OpF32> ep{ctx->cbias, nullptr, 0, ctx->cobj, 0, d, ACT_NONE};
+  HIPCHK(ctx, gemm128<OpF32>(ga, ep, st));
+  HIPCHK(ctx, hipGetLastError());
+  ctx->cond_set = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one denoiser evaluation = the kernel sequence below (captured into a hipGraph by the sampling loop)
+// ------------------------------------------------------------------------------------------------
+template <class Op>
+static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_in) {
+  typedef typename Op::elem_t E;
+  const int d = ctx->d, ff = ctx->ff, B = ctx->B, T = ctx->T, S = ctx->S, Sp = ctx->Sp, M = ctx->M, P = ctx->P;
+  int nk = 0;
+  {
+    const int rows = P + (Sp - S);
+    hipLaunchKernelGGL((prefix_fill_kernel<Op>), grid1d((long)B * rows * (d / 8)), dim3(256), 0, st, ctx->X, (E*)ctx->X_op.p,
+                       ctx->X_op.ps, ctx->temb, ctx->tcur, ctx->pstatic, B, d, P, ctx->has_t, S, Sp);
+    ++nk;
+  }
+  {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
+    GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->xs_op.ps, ctx->XK, (const E*)ctx->Wfused.p, ctx->Wfused.ps, ctx->XK, B * T, d, ctx->XK};
+    EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, ctx->h1_op.ps, d, ACT_SILU};
+    HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+    ++nk;
+  }
+  {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
+    GemmArgs<Op> ga{(const E*)ctx->h1_op.p, ctx->h1_op.ps, d, (const E*)ctx->Wm2.p, ctx->Wm2.ps, d, B * T, d, d};
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, d, T, Sp, P};
+    HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+    ++nk;
+  }
+  const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
+  for (int l = 0; l < ctx->L; ++l) {
+    const LayerW& w = ctx->layers[l];
+    {
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.Win.p, w.Win.ps, d, M, 3 * d, d};
+      EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, ctx->QK_op.ps, (E*)ctx->Vt_op.p, ctx->Vt_op.ps, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
+      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      ++nk;
+    }
+    {
+      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, ctx->QK_op.ps, (const E*)ctx->Vt_op.p, ctx->Vt_op.ps, (E*)ctx->A_op.p, ctx->A_op.ps, S, Sp, ctx->Skp, d, ctx->H};
+      HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
+      ++nk;
+    }
+    {
+      GemmArgs<Op> ga{(const E*)ctx->A_op.p, ctx->A_op.ps, d, (const E*)w.Wout.p, w.Wout.ps, d, M, d, d};
+      EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
+      HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+      ++nk;
+    }
+    {
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.W1.p, w.W1.ps, d, M, ff, d};
+      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ctx->H_op.ps, ff, ACT_GELU};
+      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      ++nk;
+    }
+    {
+      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ctx->H_op.ps, ff, (const E*)w.W2.p, w.W2.ps, ff, M, d, ff};
+      EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
+      HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+      ++nk;
+    }
+  }
+  {
+    GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)ctx->Wf.p, ctx->Wf.ps, d, M, ctx->XN, d};
+    HIPCHK(ctx, gemm128<Op>(ga, head_in, st));
+    ++nk;
+  }
+  ctx->step_kernels = nk;
+  return 0;
+}
+
+template <class Op>
+static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
+  EpiHead<Op> h{};
+  h.bias = ctx->bf;
+  h.mode = mode;
+  h.F = ctx->F;
+  h.T = ctx->T;
+  h.Sp = ctx->Sp;
+  h.P = ctx->P;
+  h.XK = ctx->XK;
+  h.xs = ctx->xs;
+  h.xs_op = (typename Op::elem_t*)ctx->xs_op.p;
+  h.xs_op_ps = ctx->xs_op.ps;
+  h.tcur = ctx->tcur;
+  h.c1 = ctx->c1;
+  h.c2 = ctx->c2;
+  h.sigma = ctx->sigma;
+  h.n_steps = ctx->n_steps;
+  h.noise_draw_stride = (long)ctx->B * ctx->F * ctx->T;
+  return h;
+}
+
+template <class Op>
+static int denoise_impl(tamf_ctx* ctx, const float* x, const int64_t* t_dev, float* out, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  const int B = ctx->B, T = ctx->T;
+  hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x, ctx->xs, (E*)ctx->xs_op.p,
+                     ctx->xs_op.ps, B, ctx->F, T, ctx->XK, 0, 0ull, 0ll);
+  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)t_dev, 0, B);
+  EpiHead<Op> h = make_head<Op>(ctx, HEAD_X0);
+  h.x0_out = out;
+  TRY(enqueue_step<Op>(ctx, st, h));
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+extern "C" int tamf_denoise(tamf_ctx* ctx, const float* x_dev, const int64_t* t_dev, float* x0_out_dev, void* stream) {
+  if (!ctx || !x_dev || !t_dev || !x0_out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
+  if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
+  if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "tamf_denoise needs a G context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (ctx->prec) {
+    case TAMF_PREC_F32: return denoise_impl<OpF32>(ctx, x_dev, t_dev, x0_out_dev, st);
+    case TAMF_PREC_BF16: return denoise_impl<OpBF16>(ctx, x_dev, t_dev, x0_out_dev, st);
+    default: return denoise_impl<OpBF16X3>(ctx, x_dev, t_dev, x0_out_dev, st);
+  }
+}
+
+template <class Op>
+static int refine_impl(tamf_ctx* ctx, const float* x_in, const float* h2o, float* out, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  const int B = ctx->B, T = ctx->T;
+  hipLaunchKernelGGL((refine_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x_in, h2o, (E*)ctx->xs_op.p,
+                     ctx->xs_op.ps, B * T, ctx->F, ctx->arch.h2o_dim, ctx->XK);
+  EpiHead<Op> h = make_head<Op>(ctx, HEAD_RESIDUAL);
+  h.x0_out = out;
+  h.x_in = x_in;
+  TRY(enqueue_step<Op>(ctx, st, h));
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+extern "C" int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
+                           void* stream) {
+  if (!ctx || !sample_pose_repr_dev || !h2o_dist_dev || !out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
+  if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
+  if (ctx->arch.kind != TAMF_KIND_R) return fail(ctx, TAMF_ERR_STATE, "tamf_refine needs an R context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (ctx->prec) {
+    case TAMF_PREC_F32: return refine_impl<OpF32>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
+    case TAMF_PREC_BF16: return refine_impl<OpBF16>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
+    default: return refine_impl<OpBF16X3>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
+  }
+}
+
+extern "C" int tamf_ddpm_step(tamf_ctx* ctx, const float* x_t_dev, const float* x0_dev, int32_t t, const float* noise_dev,
+                              float* x_out_dev, int64_t n, void* stream) {
+  if (!ctx || !x_t_dev || !x0_dev || !x_out_dev || n <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  if (ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "schedule not set");
+  if (t < 0 || t >= ctx->n_steps) return fail(ctx, TAMF_ERR_INVALID, "t out of range");
+  if (t != 0 && !noise_dev) return fail(ctx, TAMF_ERR_INVALID, "noise required for t != 0");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(ddpm_step_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x_t_dev, x0_dev, noise_dev, x_out_dev,
+                     (long)n, ctx->h_c1[t], ctx->h_c2[t], ctx->h_sigma[t], t);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+template <class Op>
+static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t clip_base, float* out, float* dump,
+                     int use_graph, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  const int B = ctx->B, T = ctx->T, N = ctx->n_steps;
+  // draw 0 = x_T
+  hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, noise, ctx->xs,
+                     (E*)ctx->xs_op.p, ctx->xs_op.ps, B, ctx->F, T, ctx->XK, noise ? 0 : 1, (unsigned long long)seed,
+                     (long long)clip_base);
+  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B);
+  EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
+  h.noise = noise;
+  h.seed = seed;
+  h.clip_base = clip_base;
+  h.dump = dump;
+  if (!use_graph) {
+    for (int i = 0; i < N; ++i) {
+      TRY(enqueue_step<Op>(ctx, st, h));
+      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B);
+    }
+  } else {
+    GraphKey key;
+    key.B = B; key.T = T; key.n_steps = N; key.noise = noise; key.dump = dump; key.seed = seed; key.clip_base = clip_base;
+    if (!(key == ctx->graph_key) || !ctx->graph_exec) {
+      if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+      if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+      HIPCHK(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+      int rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
+      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, ctx->cap_stream, ctx->tcur, B);
+      hipError_t ee = hipStreamEndCapture(ctx->cap_stream, &ctx->graph);
+      if (rc) return rc;
+      HIPCHK(ctx, ee);
+      HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
+      ctx->graph_key = key;
+    }
+    for (int i = 0; i < N; ++i) HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+  }
+  hipLaunchKernelGGL(state_out_kernel, grid1d((long)B * ctx->F * T), dim3(256), 0, st, ctx->xs, out, B, ctx->F, T, ctx->XK);
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
+extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64_t clip_id_base, float* x0_out_dev,
+                                float* dump_dev, int32_t use_graph, void* stream) {
+  if (!ctx || !x0_out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
+  if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
+  if (ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "schedule not set");
+  if (ctx->n_steps > ctx->n_t) return fail(ctx, TAMF_ERR_STATE, "schedule longer than the timestep table (max_timesteps)");
+  if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "tamf_sample_loop needs a G context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (ctx->prec) {
+    case TAMF_PREC_F32: return loop_impl<OpF32>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
+    case TAMF_PREC_BF16: return loop_impl<OpBF16>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
+    default: return loop_impl<OpBF16X3>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
+  }
+}
+
+extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level test hooks
+// ------------------------------------------------------------------------------------------------
+struct TmpBufs {
+  std::vector<void*> v;
+  ~TmpBufs() {
+    for (void* p : v) (void)hipFree(p);
+  }
+  void* get(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    v.push_back(p);
+    return p;
+  }
+};
+
+template <class Op>
+static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, const float* bias, int act, float* c,
+                          const float* resid, const float* gamma, const float* beta, bool ln, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
+  const int Kp = round_up(K, 64);
+  TmpBufs tb;
+  E* ao = (E*)tb.get((size_t)M * Kp * Op::NP * Op::EB);
+  E* wo = (E*)tb.get((size_t)N * Kp * Op::NP * Op::EB);
+  E* yo = (E*)tb.get((size_t)M * N * Op::NP * Op::EB);
+  if (!ao || !wo || !yo) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)M * (Kp / 8)), dim3(256), 0, st, a, ao, (long)M * Kp, (long)M, K, Kp);
+  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)N * (Kp / 8)), dim3(256), 0, st, w, wo, (long)N * Kp, (long)N, K, Kp);
+  GemmArgs<Op> ga{ao, (long)M * Kp, Kp, wo, (long)N * Kp, Kp, M, N, Kp};
+  hipError_t e;
+  if (ln) {
+    EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, (long)M * N, 1e-5f};
+    e = gemm_ln<Op>(ga, ep, st);
+  } else {
+    EpiStoreF32 ep{bias, c, N, act};
+    e = gemm128<Op>(ga, ep, st);
+  }
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
+  if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "sync failed");
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("gemm run: ") + hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                              const float* bias_dev, int32_t act, float* c_dev, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % 128) return fail(nullptr, TAMF_ERR_INVALID, "N must be a multiple of 128");
+  hipStream_t st = (hipStream_t)stream;
+  switch (precision) {
+    case TAMF_PREC_F32: return test_gemm_impl<OpF32>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
+    case TAMF_PREC_BF16: return test_gemm_impl<OpBF16>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
+    case TAMF_PREC_BF16X3: return test_gemm_impl<OpBF16X3>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
+    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  }
+}
+
+extern "C" int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                                 const float* bias_dev, const float* resid_dev, const float* gamma_dev,
+                                 const float* beta_dev, float* y_dev, void* stream) {
+  if (M <= 0 || K <= 0 || !(N == 128 || N == 256 || N == 512)) return fail(nullptr, TAMF_ERR_INVALID, "N must be 128/256/512");
+  hipStream_t st = (hipStream_t)stream;
+  switch (precision) {
+    case TAMF_PREC_F32: return test_gemm_impl<OpF32>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
+    case TAMF_PREC_BF16: return test_gemm_impl<OpBF16>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
+    case TAMF_PREC_BF16X3: return test_gemm_impl<OpBF16X3>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
+    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  }
+}
+
+template <class Op>
+static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* out, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  const int d = H * hd, Sp = round_up(S, 8), Skp = round_up(S, 32);
+  const long M = (long)B * Sp;
+  TmpBufs tb;
+  const size_t qk_n = (size_t)M * 2 * d, vt_n = (size_t)B * d * Skp, o_n = (size_t)M * d;
+  E* qk = (E*)tb.get(qk_n * Op::NP * Op::EB);
+  E* vt = (E*)tb.get(vt_n * Op::NP * Op::EB);
+  E* oo = (E*)tb.get(o_n * Op::NP * Op::EB);
+  float* of = (float*)tb.get(o_n * 4);
+  if (!qk || !vt || !oo || !of) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+  (void)hipMemsetAsync(vt, 0, vt_n * Op::NP * Op::EB, st);
+  const float qscale = 1.4426950408889634f / sqrtf((float)hd);
+  hipLaunchKernelGGL((qkv_pack_kernel<Op>), grid1d(M * 3 * d), dim3(256), 0, st, qkv, qk, (long)qk_n, vt, (long)vt_n, B, S, Sp, Skp, H, hd, qscale);
+  AttnArgs<Op> aa{qk, (long)qk_n, vt, (long)vt_n, oo, (long)o_n, S, Sp, Skp, d, H};
+  hipError_t e = launch_attn<Op>(aa, B, hd, st);
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("attn launch: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL((unpack_operand_kernel<Op>), grid1d(M * d), dim3(256), 0, st, oo, (long)o_n, of, M, d, d);
+  // compact [B][Sp][d] -> [B][S][d]
+  for (int b = 0; b < B; ++b)
+    (void)hipMemcpyAsync(out + (size_t)b * S * d, of + (size_t)b * Sp * d, (size_t)S * d * 4, hipMemcpyDeviceToDevice, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "sync failed");
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("attn run: ") + hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
+                                   float* out_dev, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0 || !(hd == 64 || hd == 128)) return fail(nullptr, TAMF_ERR_INVALID, "bad attention shape");
+  hipStream_t st = (hipStream_t)stream;
+  switch (precision) {
+    case TAMF_PREC_F32: return test_attn_impl<OpF32>(B, S, H, hd, qkv_dev, out_dev, st);
+    case TAMF_PREC_BF16: return test_attn_impl<OpBF16>(B, S, H, hd, qkv_dev, out_dev, st);
+    case TAMF_PREC_BF16X3: return test_attn_impl<OpBF16X3>(B, S, H, hd, qkv_dev, out_dev, st);
+    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  }
+}
+
+extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
+                                float* out_dev, void* stream) {
+  if (B <= 0 || n_feat <= 0 || T <= 0 || !out_dev) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(philox_fill_kernel, grid1d((long)B * n_feat * T), dim3(256), 0, (hipStream_t)stream, out_dev,
+                     (unsigned long long)seed, (long long)clip_id_base, (unsigned)draw, B, n_feat, T);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}

@@ -1,0 +1,234 @@
+// Small memory-bound kernels around the GEMM/attention core: layout changes at the C-ABI boundary, the
+// per-step prefix rows, the step counter, the step-invariant conditioning precompute, operand packing.
+#pragma once
+#include "tamf_device.h"
+
+// (B, F, 1, T) reference layout -> frame-major sampler state [B*T][XK] (+ operand planes); cols >= F are zero.
+// draw0 != 0: ignore x and fill with Philox draw 0 (x_T of the throughput mode).
+template <class Op>
+__global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__ xs, typename Op::elem_t* xs_op,
+                                long xs_op_ps, int B, int F, int T, int XK, int philox, unsigned long long seed,
+                                long long clip_base) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b*T + tau) * (XK/8) + cg
+  const int CG = XK / 8;
+  if (idx >= B * T * CG) return;
+  const int cg = idx % CG, bt = idx / CG;
+  const int b = bt / T, tau = bt % T;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    float val = 0.f;
+    if (c < F) {
+      if (philox) val = philox_normal_elem(seed, clip_base + b, 0u, (unsigned)(c * T + tau));
+      else val = x[((long)b * F + c) * T + tau];
+    }
+    v[j] = val;
+  }
+  float* p = xs + (long)bt * XK + cg * 8;
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  Op::template store<8>(xs_op, xs_op_ps, (long)bt * XK + cg * 8, v);
+}
+
+// frame-major state -> (B, F, 1, T)
+__global__ void state_out_kernel(const float* __restrict__ xs, float* __restrict__ out, int B, int F, int T, int XK) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b*F + c)*T + tau
+  if (idx >= B * F * T) return;
+  const int tau = idx % T, bc = idx / T;
+  const int c = bc % F, b = bc / F;
+  out[idx] = xs[((long)b * T + tau) * XK + c];
+}
+
+// R trunk input operand: [B*T][XK] = [x_in (F) | h2o (Hd) | zero pad]
+template <class Op>
+__global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __restrict__ h2o,
+                                 typename Op::elem_t* xs_op, long xs_op_ps, int BT, int F, int Hd, int XK) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int CG = XK / 8;
+  if (idx >= BT * CG) return;
+  const int cg = idx % CG, bt = idx / CG;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    float val = 0.f;
+    if (c < F) val = x_in[(long)bt * F + c];
+    else if (c < F + Hd) val = h2o[(long)bt * Hd + (c - F)];
+    v[j] = val;
+  }
+  Op::template store<8>(xs_op, xs_op_ps, (long)bt * XK + cg * 8, v);
+}
+
+// Rows the encoder input needs besides the frame tokens, every step: prefix row 0 = timestep-embedding table
+// row of the clip's current t (G), prefix rows 1.. = step-invariant tokens, pad rows [S, Sp) = 0.
+template <class Op>
+__global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* Xop, long xop_ps,
+                                   const float* __restrict__ temb, const int* __restrict__ tcur,
+                                   const float* __restrict__ pstatic, int B, int d, int P, int has_t, int S, int Sp) {
+  const int rows_per_clip = P + (Sp - S);
+  const int CG = d / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * rows_per_clip * CG) return;
+  const int cg = idx % CG, br = idx / CG;
+  const int b = br / rows_per_clip, j = br % rows_per_clip;
+  float v[8];
+  int s;
+  if (j < P) {
+    s = j;
+    const float* src;
+    if (has_t && j == 0) src = temb + (long)tcur[b] * d;
+    else src = pstatic + ((long)b * (P - has_t) + (j - has_t)) * d;
+    const float4 a = *(const float4*)(src + cg * 8), c = *(const float4*)(src + cg * 8 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  } else {
+    s = S + (j - P);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+  }
+  const long o = ((long)b * Sp + s) * d + cg * 8;
+  *(float4*)(X + o) = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(X + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  Op::template store<8>(Xop, xop_ps, o, v);
+}
+
+__global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tcur[i] = t_dev ? (int)t_dev[i] : uniform_t;
+}
+__global__ void advance_t_kernel(int* tcur, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tcur[i] -= 1;
+}
+
+// out[o][i] = mean_m in[o][m][i]   (torch.mean: sum / n)
+__global__ void mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int outer, int nmid, int inner) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)outer * inner) return;
+  const int i = (int)(idx % inner);
+  const long o = idx / inner;
+  float s = 0.f;
+  for (int m = 0; m < nmid; ++m) s += in[(o * nmid + m) * inner + i];
+  out[idx] = s / (float)nmid;
+}
+
+// out[r][n] = sum_k in[r][k] * W[n][k] + bias[n]  (tiny K; one thread per output)
+__global__ void linear_small_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                    const float* __restrict__ bias, float* __restrict__ out, long R, int N, int K) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * N) return;
+  const int n = (int)(idx % N);
+  const long r = idx / N;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(in[r * K + k], W[(long)n * K + k], s);
+  out[idx] = s + (bias ? bias[n] : 0.f);
+}
+
+// pstatic[b][j][:] = nan_to_num(e_j[b][:]) + pe[(j0 + j)][:]
+__global__ void prefix_pack_kernel(const float* __restrict__ e, float* __restrict__ pstatic, const float* __restrict__ pe,
+                                   int B, int d, int nrows, int j, int pe_row) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * d) return;
+  const int c = idx % d, b = idx / d;
+  pstatic[((long)b * nrows + j) * d + c] = nan_to_num(e[idx]) + pe[(long)pe_row * d + c];
+}
+
+// hand_side token: "rh" -> rh_embed, "lh" -> lh_embed
+__global__ void hand_side_kernel(const unsigned char* __restrict__ side, const float* __restrict__ rh,
+                                 const float* __restrict__ lh, float* __restrict__ out, int B, int d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * d) return;
+  const int c = idx % d, b = idx / d;
+  out[idx] = side[b] ? lh[c] : rh[c];
+}
+
+// fp32 [R][C] -> operand planes [NP][R][ldo] (cols >= C zero-filled up to ldo)
+template <class Op>
+__global__ void pack_operand_kernel(const float* __restrict__ in, typename Op::elem_t* out, long out_ps, long R, int C,
+                                    int ldo) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CG = ldo / 8;
+  if (idx >= R * CG) return;
+  const int cg = (int)(idx % CG);
+  const long r = idx / CG;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    v[j] = c < C ? in[r * C + c] : 0.f;
+  }
+  Op::template store<8>(out, out_ps, r * ldo + cg * 8, v);
+}
+
+// test hook: packed [B][S][3*H*hd] fp32 -> QK operand [B*Sp][2d] (Q scaled) and V^T operand
+template <class Op>
+__global__ void qkv_pack_kernel(const float* __restrict__ qkv, typename Op::elem_t* qk, long qk_ps,
+                                typename Op::elem_t* vt, long vt_ps, int B, int S, int Sp, int Skp, int H, int hd,
+                                float qscale) {
+  const int d = H * hd;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Sp * 3 * d) return;
+  const int c = (int)(idx % (3 * d));
+  const long bs = idx / (3 * d);
+  const int s = (int)(bs % Sp), b = (int)(bs / Sp);
+  float v = 0.f;
+  if (s < S) v = qkv[((long)b * S + s) * 3 * d + c];
+  float one[2] = {v, 0.f};
+  if (c < 2 * d) {
+    if (c < d) one[0] = v * qscale;
+    // store a single element per plane
+    if constexpr (Op::EB == 4) {
+      ((float*)qk)[bs * 2 * d + c] = one[0];
+    } else {
+      const uint32_t hi = f2bf(one[0]);
+      ((uint16_t*)qk)[bs * 2 * d + c] = (uint16_t)hi;
+      if constexpr (Op::NP == 2) ((uint16_t*)qk)[qk_ps + bs * 2 * d + c] = (uint16_t)f2bf(one[0] - bf2f(hi));
+    }
+  } else {
+    const int eg = c - 2 * d, h = eg / hd, e = eg % hd;
+    const long o = ((long)(b * H + h) * hd + e) * Skp + s;
+    if constexpr (Op::EB == 4) {
+      ((float*)vt)[o] = v;
+    } else {
+      const uint32_t hi = f2bf(v);
+      ((uint16_t*)vt)[o] = (uint16_t)hi;
+      if constexpr (Op::NP == 2) ((uint16_t*)vt)[vt_ps + o] = (uint16_t)f2bf(v - bf2f(hi));
+    }
+  }
+}
+
+// operand planes [NP][R][ld] -> fp32 (test hook; x3: hi + lo)
+template <class Op>
+__global__ void unpack_operand_kernel(const typename Op::elem_t* in, long in_ps, float* __restrict__ out, long R, int C,
+                                      int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * C) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  if constexpr (Op::EB == 4) {
+    out[idx] = ((const float*)in)[r * ld + c];
+  } else {
+    float v = bf2f(((const uint16_t*)in)[r * ld + c]);
+    if constexpr (Op::NP == 2) v += bf2f(((const uint16_t*)in)[in_ps + r * ld + c]);
+    out[idx] = v;
+  }
+}
+
+// x_{t-1} = coef1 x0 + coef2 x_t + [t != 0] sigma eps   (standalone form of the fused update)
+__global__ void ddpm_step_kernel(const float* __restrict__ xt, const float* __restrict__ x0,
+                                 const float* __restrict__ noise, float* __restrict__ out, long n, float k1, float k2,
+                                 float sg, int t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = __fadd_rn(__fmul_rn(k1, x0[i]), __fmul_rn(k2, xt[i]));
+  if (t != 0) r = __fadd_rn(r, __fmul_rn(sg, noise[i]));
+  out[i] = r;
+}
+
+__global__ void philox_fill_kernel(float* out, unsigned long long seed, long long clip_base, unsigned draw, int B,
+                                   int F, int T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F * T) return;
+  const int e = idx % (F * T), b = idx / (F * T);
+  out[idx] = philox_normal_elem(seed, clip_base + b, draw, (unsigned)e);
+}

@@ -1,0 +1,67 @@
+"""Locate / build / load libtamf_hip.so (the C-ABI of include/tamf_hip.h)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "..", "include"))
+LIB_PATH = os.path.join(_HERE, "lib", "libtamf_hip.so")
+SOURCES = ["tamf_hip.hip", "tamf_device.h", "tamf_gemm.h", "tamf_attn.h", "tamf_misc.h"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+class TamfBuildError(RuntimeError):
+    pass
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(INCLUDE, "tamf_hip.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -shared; cross-compiles without a GPU.  Returns the .so path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise TamfBuildError("hipcc not found: cannot build libtamf_hip.so")
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", tmp, os.path.join(CSRC, "tamf_hip.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise TamfBuildError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    if verbose:
+        print("built", LIB_PATH)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the library (building it first if the in-tree .so is missing or older than its sources).
+    Raises - never falls back to a CPU path."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            build()
+            _lib = ctypes.CDLL(LIB_PATH)
+        return _lib
+
+
+EXPORTS = [
+    "tamf_ctx_create", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
+    "tamf_set_schedule", "tamf_set_cond", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
+    "tamf_step_kernel_count", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox",
+]

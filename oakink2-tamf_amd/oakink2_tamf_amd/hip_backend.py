@@ -1,0 +1,282 @@
+"""ctypes binding of include/tamf_hip.h.  PyTorch is used only for device memory and streams."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint64, c_void_p
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+KINDS = {"G": 0, "R": 1}
+
+
+class TamfError(RuntimeError):
+    pass
+
+
+class _Arch(ctypes.Structure):
+    _fields_ = [
+        ("input_dim", c_int32),
+        ("obj_input_dim", c_int32),
+        ("hand_shape_dim", c_int32),
+        ("obj_embed_dim", c_int32),
+        ("latent_dim", c_int32),
+        ("ff_size", c_int32),
+        ("num_layers", c_int32),
+        ("num_heads", c_int32),
+        ("clip_dim", c_int32),
+        ("h2o_dim", c_int32),
+        ("kind", c_int32),
+    ]
+
+
+_bound = False
+
+
+def lib() -> ctypes.CDLL:
+    global _bound
+    L = _lib.load()
+    if not _bound:
+        L.tamf_last_error.restype = c_char_p
+        L.tamf_last_error.argtypes = [c_void_p]
+        L.tamf_ctx_create.argtypes = [POINTER(_Arch), c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        L.tamf_ctx_destroy.argtypes = [c_void_p]
+        L.tamf_ctx_destroy.restype = None
+        L.tamf_load_weight.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
+        L.tamf_finalize_weights.argtypes = [c_void_p, c_int32, c_void_p]
+        L.tamf_set_schedule.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
+        L.tamf_set_cond.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.tamf_denoise.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
+        L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
+        L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.tamf_step_kernel_count.argtypes = [c_void_p]
+        L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
+        L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
+        L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+        L.tamf_test_philox.argtypes = [c_uint64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+        _bound = True
+    return L
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check(rc: int, ctx=None):
+    if rc != 0:
+        msg = lib().tamf_last_error(ctx)
+        raise TamfError(f"libtamf_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise TamfError("no MI355X/HIP device visible: the MF-MDM HIP path has no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise TamfError(f"HIP path needs a cuda (ROCm) device, got {dev}")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class TamfContext:
+    """One library context = one (model, device, precision, max batch, max frames)."""
+
+    def __init__(self, arch: Mapping[str, int], max_batch: int, max_frames: int, precision: str = "f32",
+                 device=None, kind: str = "G"):
+        self.device = require_gpu(device)
+        self.precision = precision
+        self.kind = kind
+        a = _Arch(
+            input_dim=int(arch.get("input_dim", 99)),
+            obj_input_dim=int(arch.get("obj_input_dim", 9)),
+            hand_shape_dim=int(arch.get("hand_shape_dim", 10)),
+            obj_embed_dim=int(arch.get("obj_embed_dim", 768)),
+            latent_dim=int(arch.get("latent_dim", 256)),
+            ff_size=int(arch.get("ff_size", 1024)),
+            num_layers=int(arch.get("num_layers", 8)),
+            num_heads=int(arch.get("num_heads", 4)),
+            clip_dim=int(arch.get("clip_dim", 512)),
+            h2o_dim=int(arch.get("h2o_dim", 778)),
+            kind=KINDS[kind],
+        )
+        self.input_dim = a.input_dim
+        self.h2o_dim = a.h2o_dim
+        self.max_batch, self.max_frames = int(max_batch), int(max_frames)
+        self._h = c_void_p()
+        self.B = self.T = 0
+        self.n_steps = 0
+        self._keep = []
+        with torch.cuda.device(self.device):
+            _check(lib().tamf_ctx_create(ctypes.byref(a), max_batch, max_frames, PRECISIONS[precision],
+                                         self.device.index, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().tamf_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], max_timesteps: int = 1000):
+        L = lib()
+        for name, t in sd.items():
+            if not isinstance(t, torch.Tensor) or name.startswith("clip_model."):
+                continue
+            h = t.detach().to("cpu", torch.float32).contiguous()
+            shape = (c_int64 * max(h.dim(), 1))(*(list(h.shape) or [1]))
+            _check(L.tamf_load_weight(self._h, name.encode(), c_void_p(h.data_ptr()), shape, max(h.dim(), 1)), self._h)
+        with torch.cuda.device(self.device):
+            _check(L.tamf_finalize_weights(self._h, int(max_timesteps), c_void_p(_stream_ptr(self.device))), self._h)
+
+    def set_schedule(self, coef1: np.ndarray, coef2: np.ndarray, log_variance_clipped: np.ndarray):
+        c1 = np.ascontiguousarray(coef1, dtype=np.float64)
+        c2 = np.ascontiguousarray(coef2, dtype=np.float64)
+        lv = np.ascontiguousarray(log_variance_clipped, dtype=np.float64)
+        assert c1.shape == c2.shape == lv.shape and c1.ndim == 1
+        self.n_steps = int(c1.shape[0])
+        _check(lib().tamf_set_schedule(self._h, self.n_steps, c1.ctypes.data_as(c_void_p), c2.ctypes.data_as(c_void_p),
+                                       lv.ctypes.data_as(c_void_p)), self._h)
+
+    # -- conditioning -------------------------------------------------------------------------
+    def set_cond(self, text_embedding: Optional[torch.Tensor], hand_side: Sequence, shape: torch.Tensor,
+                 obj_embedding: torch.Tensor, obj_traj: torch.Tensor):
+        side = []
+        for hs in hand_side:
+            if hs == "rh" or (not isinstance(hs, str) and int(hs) == 0):
+                side.append(0)
+            elif hs == "lh" or (not isinstance(hs, str) and int(hs) == 1):
+                side.append(1)
+            else:
+                raise ValueError(f"unexpected hand_side: {hs}")
+        B, nobj, T, _ = obj_traj.shape
+        dev = self.device
+        te = _dev_f32(text_embedding, dev) if text_embedding is not None else None
+        sh, oe, ot = _dev_f32(shape, dev), _dev_f32(obj_embedding, dev), _dev_f32(obj_traj, dev)
+        assert sh.shape[0] == B and sh.shape[1] == T and oe.shape[0] == B and oe.shape[1] == nobj
+        side_np = np.asarray(side, dtype=np.uint8)
+        assert side_np.shape[0] == B
+        with torch.cuda.device(dev):
+            _check(lib().tamf_set_cond(self._h, B, T, nobj, c_void_p(te.data_ptr() if te is not None else 0),
+                                       side_np.ctypes.data_as(c_void_p), c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()),
+                                       c_void_p(ot.data_ptr()), c_void_p(_stream_ptr(dev))), self._h)
+        self._keep = [te, sh, oe, ot]
+        self.B, self.T = int(B), int(T)
+
+    # -- compute ------------------------------------------------------------------------------
+    def denoise(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        dev = self.device
+        xd = _dev_f32(x, dev)
+        assert tuple(xd.shape) == (self.B, self.input_dim, 1, self.T), (tuple(xd.shape), self.B, self.T)
+        td = t.detach().to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty_like(xd)
+        with torch.cuda.device(dev):
+            _check(lib().tamf_denoise(self._h, c_void_p(xd.data_ptr()), c_void_p(td.data_ptr()), c_void_p(out.data_ptr()),
+                                      c_void_p(_stream_ptr(dev))), self._h)
+        return out
+
+    def ddpm_step(self, x_t: torch.Tensor, x0: torch.Tensor, t: int, noise: Optional[torch.Tensor]) -> torch.Tensor:
+        dev = self.device
+        xt, x0d = _dev_f32(x_t, dev), _dev_f32(x0, dev)
+        nz = _dev_f32(noise, dev) if noise is not None else None
+        out = torch.empty_like(xt)
+        with torch.cuda.device(dev):
+            _check(lib().tamf_ddpm_step(self._h, c_void_p(xt.data_ptr()), c_void_p(x0d.data_ptr()), int(t),
+                                        c_void_p(nz.data_ptr() if nz is not None else 0), c_void_p(out.data_ptr()),
+                                        xt.numel(), c_void_p(_stream_ptr(dev))), self._h)
+        return out
+
+    def sample_loop(self, noise: Optional[torch.Tensor] = None, seed: int = 0, clip_id_base: int = 0,
+                    dump: bool = False, use_graph: bool = True, out: Optional[torch.Tensor] = None):
+        """noise: (n_steps+1, B, F, 1, T) draws in reference call order, or None for device Philox."""
+        dev = self.device
+        shape = (self.B, self.input_dim, 1, self.T)
+        nz = None
+        if noise is not None:
+            nz = _dev_f32(noise, dev)
+            assert tuple(nz.shape) == (self.n_steps + 1,) + shape, (tuple(nz.shape), shape)
+        if out is None:
+            out = torch.empty(shape, device=dev, dtype=torch.float32)
+        dmp = torch.empty((self.n_steps,) + shape, device=dev, dtype=torch.float32) if dump else None
+        with torch.cuda.device(dev):
+            _check(lib().tamf_sample_loop(self._h, c_void_p(nz.data_ptr() if nz is not None else 0), int(seed) & (2**64 - 1),
+                                          int(clip_id_base), c_void_p(out.data_ptr()),
+                                          c_void_p(dmp.data_ptr() if dmp is not None else 0), 1 if use_graph else 0,
+                                          c_void_p(_stream_ptr(dev))), self._h)
+        self._keep_loop = [nz, dmp]
+        return (out, dmp) if dump else out
+
+    def refine(self, sample_pose_repr: torch.Tensor, h2o_dist: torch.Tensor) -> torch.Tensor:
+        dev = self.device
+        xin, h2o = _dev_f32(sample_pose_repr, dev), _dev_f32(h2o_dist, dev)
+        assert tuple(xin.shape) == (self.B, self.T, self.input_dim)
+        assert tuple(h2o.shape) == (self.B, self.T, self.h2o_dim)
+        out = torch.empty_like(xin)
+        with torch.cuda.device(dev):
+            _check(lib().tamf_refine(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()),
+                                     c_void_p(_stream_ptr(dev))), self._h)
+        return out
+
+    @property
+    def step_kernel_count(self) -> int:
+        return int(lib().tamf_step_kernel_count(self._h))
+
+
+# ---- kernel-level test hooks ---------------------------------------------------------------------
+
+
+def test_gemm(precision: str, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
+    dev = require_gpu(a.device)
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), device=dev, dtype=torch.float32)
+    a, w = _dev_f32(a, dev), _dev_f32(w, dev)
+    b = _dev_f32(bias, dev) if bias is not None else None
+    _check(lib().tamf_test_gemm(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
+                                c_void_p(b.data_ptr() if b is not None else 0), act, c_void_p(c.data_ptr()),
+                                c_void_p(_stream_ptr(dev))))
+    return c
+
+
+def test_gemm_ln(precision: str, a, w, bias, resid, gamma, beta) -> torch.Tensor:
+    dev = require_gpu(a.device)
+    M, K = a.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=dev, dtype=torch.float32)
+    ts = [_dev_f32(t, dev) for t in (a, w, bias, resid, gamma, beta)]
+    _check(lib().tamf_test_gemm_ln(PRECISIONS[precision], M, N, K, *[c_void_p(t.data_ptr()) for t in ts],
+                                   c_void_p(y.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return y
+
+
+def test_attention(precision: str, qkv: torch.Tensor, H: int) -> torch.Tensor:
+    dev = require_gpu(qkv.device)
+    B, S, D3 = qkv.shape
+    d = D3 // 3
+    out = torch.empty((B, S, d), device=dev, dtype=torch.float32)
+    q = _dev_f32(qkv, dev)
+    _check(lib().tamf_test_attention(PRECISIONS[precision], B, S, H, d // H, c_void_p(q.data_ptr()), c_void_p(out.data_ptr()),
+                                     c_void_p(_stream_ptr(dev))))
+    return out
+
+
+def test_philox(seed: int, clip_id_base: int, draw: int, B: int, F: int, T: int, device=None) -> torch.Tensor:
+    dev = require_gpu(device)
+    out = torch.empty((B, F, 1, T), device=dev, dtype=torch.float32)
+    _check(lib().tamf_test_philox(seed, clip_id_base, draw, B, F, T, c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    torch.cuda.synchronize(dev)
+    return out

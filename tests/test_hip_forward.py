@@ -1,0 +1,178 @@
+"""GPU: the HIP denoiser / DDPM loop through the C-ABI against the golden vectors captured from the reference
+and against the oracle on the same inputs.
+
+Stated fp32 tolerances (max abs, outputs are O(1)):
+  f32    : forward 2e-5, loops 5e-5          (exact-fp32 MFMA; only summation order differs from torch-CPU)
+  bf16x3 : forward 5e-4, loops 1e-3          (split-bf16 operands, fp32 accumulate)
+  bf16   : forward 6e-2 (reported, bf16 operands); loops 1e-1
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cond, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = {"f32": 2e-5, "bf16x3": 5e-4, "bf16": 6e-2}
+LOOP_TOL = {"f32": 5e-5, "bf16x3": 1e-3, "bf16": 1e-1}
+
+
+def _arch_dict(a):
+    return dict(input_dim=a.input_dim, obj_input_dim=a.obj_input_dim, hand_shape_dim=a.hand_shape_dim,
+                obj_embed_dim=a.obj_embed_dim, latent_dim=a.latent_dim, ff_size=a.ff_size, num_layers=a.num_layers,
+                num_heads=a.num_heads, clip_dim=a.clip_dim, h2o_dim=a.h2o_dim)
+
+
+def _make_ctx(arch, sd, B, T, prec, n_steps=1000):
+    from oakink2_tamf_amd.hip_backend import TamfContext
+    from oracle import mdm_oracle as O
+
+    ctx = TamfContext(_arch_dict(arch), B, T, precision=prec, kind=arch.kind)
+    ctx.load_state_dict(sd, max_timesteps=max(n_steps, 1000))
+    tab = O.make_tables(n_steps, "cosine")
+    ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+    return ctx
+
+
+def _set_cond(ctx, cond):
+    ctx.set_cond(cond.get("text_embedding"), cond["hand_side"], cond["shape"], cond["obj_embedding"], cond["obj_traj"])
+
+
+FWD_CASES = ["tiny", "tiny_ragged", "tiny_nonfinite", "arch_mdm", "arch_mdm_l", "arch_mdm_l_t196"]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("name", FWD_CASES)
+def test_forward_golden(name, prec):
+    from oracle import mdm_oracle as O
+
+    arch = {"tiny": O.ARCH_TINY, "tiny_ragged": O.ARCH_TINY, "tiny_nonfinite": O.ARCH_TINY, "arch_mdm": O.ARCH_MDM,
+            "arch_mdm_l": O.ARCH_MDM_L, "arch_mdm_l_t196": O.ARCH_MDM_L}[name]
+    fix = load_golden(f"forward_{name}.npz")
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    x = torch.from_numpy(fix["x"])
+    B, _, _, T = x.shape
+    ctx = _make_ctx(arch, sd, B, T, prec)
+    _set_cond(ctx, cond)
+    for t in fix["ts"]:
+        out = ctx.denoise(x, torch.full((B,), int(t), dtype=torch.long)).cpu().numpy()
+        ref = fix[f"out/t{int(t)}"]
+        assert np.isfinite(out).all()
+        err = np.abs(out - ref).max()
+        assert err < FWD_TOL[prec], (name, prec, int(t), err)
+    out = ctx.denoise(x, torch.from_numpy(fix["ts_mixed"])).cpu().numpy()
+    assert np.abs(out - fix["out/mixed"]).max() < FWD_TOL[prec]
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_loop_tiny_10_every_step(prec, use_graph):
+    from oracle import mdm_oracle as O
+
+    fix = load_golden("loop_tiny_10.npz")
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="tiny_10/w")
+    cond = golden_cond(fix)
+    draws = torch.from_numpy(fix["draws"])  # (11, 2, 99, 1, 16)
+    ctx = _make_ctx(arch, sd, 2, 16, prec, n_steps=10)
+    _set_cond(ctx, cond)
+    out, dump = ctx.sample_loop(noise=draws, dump=True, use_graph=use_graph)
+    dump = dump.cpu().numpy()
+    for s in fix["dump_steps"]:
+        err = np.abs(dump[int(s)] - fix[f"dump/{int(s)}"]).max()
+        assert err < LOOP_TOL[prec], (prec, int(s), err)
+    np.testing.assert_array_equal(out.cpu().numpy(), dump[-1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_loop_config0_arch_mdm_b4_t64_50(prec):
+    """BASELINE.json configs[0] on the GPU path: arch_mdm, B=4, T=64, 50 steps, noise in reference call order."""
+    from oracle import det
+    from oracle import mdm_oracle as O
+
+    name = "arch_mdm_b4_t64_50"
+    fix = load_golden(f"loop_{name}.npz")
+    arch = O.ARCH_MDM
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (4, 99, 1, 64)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape) for k in range(51)]))
+    ctx = _make_ctx(arch, sd, 4, 64, prec, n_steps=50)
+    _set_cond(ctx, cond)
+    out = ctx.sample_loop(noise=draws).cpu().numpy()
+    err = np.abs(out - fix["final"]).max()
+    assert err < LOOP_TOL[prec], (prec, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_loop_tiny_1000(prec):
+    from oracle import det
+    from oracle import mdm_oracle as O
+
+    name = "tiny_1000"
+    fix = load_golden(f"loop_{name}.npz")
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 16)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape) for k in range(1001)]))
+    ctx = _make_ctx(arch, sd, 2, 16, prec, n_steps=1000)
+    _set_cond(ctx, cond)
+    out = ctx.sample_loop(noise=draws).cpu().numpy()
+    err = np.abs(out - fix["final"]).max()
+    assert err < LOOP_TOL[prec], (prec, err)
+    ctx.close()
+
+
+def test_philox_loop_matches_oracle_and_is_shard_independent():
+    """Throughput-mode noise: the device Philox stream equals the oracle's restatement, and a clip's result does
+    not depend on which shard (clip_id_base, batch position) it was sampled in."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="philox/w")
+    B, T, N, seed = 4, 16, 8, 99
+    cond = O.det_cond(B, T, tag="philox/c", arch=arch)
+    ctx = _make_ctx(arch, sd, B, T, "f32", n_steps=N)
+    _set_cond(ctx, cond)
+    full = ctx.sample_loop(noise=None, seed=seed, clip_id_base=100).cpu().numpy()
+    tab = O.make_tables(N, "cosine")
+    ref = O.sample_loop(sd, arch, tab, cond, (B, 99, 1, T),
+                        lambda k: torch.from_numpy(O.philox_normal(seed, np.arange(100, 100 + B), k, 99, T)))
+    assert np.abs(full - ref.numpy()).max() < 2e-4
+    # second shard alone: clips 102, 103
+    sub = {k: (v[2:] if not isinstance(v, list) else v[2:]) for k, v in cond.items()}
+    _set_cond(ctx, sub)
+    part = ctx.sample_loop(noise=None, seed=seed, clip_id_base=102).cpu().numpy()
+    assert np.abs(part - full[2:]).max() < 1e-5
+    ctx.close()
+
+
+def test_error_paths():
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfError
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY
+    with pytest.raises(TamfError):
+        TamfContext(dict(_arch_dict(arch), latent_dim=96), 1, 8)
+    ctx = TamfContext(_arch_dict(arch), 2, 16)
+    sd = O.det_state_dict(arch)
+    bad = dict(sd)
+    bad.pop("embed_text.weight")
+    with pytest.raises(TamfError, match="missing checkpoint tensor"):
+        ctx.load_state_dict(bad)
+    ctx.close()
+    ctx = TamfContext(_arch_dict(arch), 2, 16)
+    ctx.load_state_dict(sd)
+    cond = O.det_cond(2, 16, arch=arch)
+    cond["hand_side"] = ["rh", "both"]
+    with pytest.raises(ValueError):
+        _set_cond(ctx, cond)
+    with pytest.raises(TamfError):
+        ctx.denoise(torch.zeros(2, 99, 1, 16), torch.zeros(2, dtype=torch.long))  # cond not set
+    ctx.close()

@@ -1,0 +1,109 @@
+"""GPU: kernel-level parity of the HIP building blocks (through the C-ABI test hooks) against float64 torch-CPU.
+
+Tolerances are relative to the natural scale of each result:
+  f32    exact-fp32 MFMA (k-ordered fmaf chain): 2e-6 * sum|a||w| bound -> checked as 1e-5 relative
+  bf16x3 split-bf16, ~2^-17 operand error: 1e-4 relative
+  bf16   8-bit mantissa operands: 2e-2 relative
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}
+
+
+def _rel(got, ref):
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.fixture(scope="module")
+def hb():
+    from oakink2_tamf_amd import hip_backend
+
+    hip_backend.require_gpu()
+    return hip_backend
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 192, 0), (128, 128, 64, 1), (1000, 384, 512, 2), (77, 128, 99, 0)])
+def test_gemm(hb, prec, M, N, K, act):
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = ref * torch.sigmoid(ref)
+    elif act == 2:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2.0)))
+    got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), act)
+    assert _rel(got, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_gemm_asymmetric_identity(hb, prec):
+    """A = I against an asymmetric integer W catches a transposed accumulator layout exactly."""
+    K = 128
+    a = torch.eye(K)
+    w = (torch.arange(256 * K).reshape(256, K) % 13 - 6).float() + (torch.arange(256).reshape(256, 1) % 5).float()
+    got = hb.test_gemm(prec, a.cuda(), w.cuda(), None, 0).cpu()
+    assert torch.equal(got, w.t().contiguous())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(200, 128, 128), (333, 256, 1024), (130, 512, 512), (64, 512, 2048)])
+def test_gemm_residual_layernorm(hb, prec, M, N, K):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    ga = 1 + 0.1 * torch.randn(N, generator=g)
+    be = 0.1 * torch.randn(N, generator=g)
+    v = (a.double() @ w.double().t() + b.double()) + r.double()
+    ref = torch.nn.functional.layer_norm(v, (N,), ga.double(), be.double(), 1e-5)
+    got = hb.test_gemm_ln(prec, a.cuda(), w.cuda(), b.cuda(), r.cuda(), ga.cuda(), be.cuda())
+    assert _rel(got, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,S,H,hd", [(2, 69, 4, 64), (2, 201, 4, 128), (3, 21, 2, 64), (1, 165, 4, 128), (2, 32, 1, 128)])
+def test_attention(hb, prec, B, S, H, hd):
+    g = torch.Generator().manual_seed(3)
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, generator=g)
+    q, k, v = qkv.double().split(d, dim=-1)
+    q = q.view(B, S, H, hd).transpose(1, 2)
+    k = k.view(B, S, H, hd).transpose(1, 2)
+    v = v.view(B, S, H, hd).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, S, d)
+    got = hb.test_attention(prec, qkv.cuda(), H)
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
+
+
+def test_attention_online_softmax_rescale(hb):
+    """A late key block carrying the row maximum forces the running-max rescale path."""
+    B, S, H, hd = 1, 201, 1, 128
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, S, 3 * hd, generator=g)
+    qkv[0, 190, hd : 2 * hd] = qkv[0, 7, 0:hd] * 4.0  # key 190 aligned with query 7 -> huge score in the last block
+    q, k, v = qkv.double().split(hd, dim=-1)
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+    ref = att @ v
+    got = hb.test_attention("f32", qkv.cuda(), H)
+    assert _rel(got, ref) < 2e-5
+
+
+def test_philox_matches_oracle(hb):
+    from oracle import mdm_oracle as O
+
+    got = hb.test_philox(1234567890123, 40, 3, 4, 99, 64).cpu().numpy()
+    ref = O.philox_normal(1234567890123, np.arange(40, 44), 3, 99, 64)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    assert abs(got.mean()) < 0.03 and abs(got.std() - 1) < 0.03
