@@ -125,8 +125,13 @@ int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64
 int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
                 void* stream);
 
-/* Introspection for bench / profiles: name + grid of the kernels one denoiser step launches. */
+/* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);
+/* Runs ONE denoiser step (DDPM update at t = n_steps/2, Philox noise; the sampler state is advanced by it) kernel by
+ * kernel with hipEvents recorded on `stream` after every launch, synchronises, and reports per launch: elapsed
+ * milliseconds, the algorithmic FLOPs of the reference work it stands for, and a name
+ * (names_host: max_n x 48 chars).  Returns the number of launches (>= 0) or a negative tamf_status. */
+int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host, void* stream);
 
 /* ---- kernel-level test hooks (used by tests/ only; same kernels the step uses) ------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, optional activation (0 none, 1 silu, 2 gelu_erf); all f32 device buffers;

@@ -86,6 +86,11 @@ struct tamf_ctx {
   hipGraphExec_t graph_exec = nullptr;
   GraphKey graph_key;
   int step_kernels = 0;
+  // per-launch profiling (tamf_step_profile)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<std::string> prof_names;
+  std::vector<double> prof_flops;
 };
 
 static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
@@ -258,8 +263,10 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (arch->kind != TAMF_KIND_G && arch->kind != TAMF_KIND_R) return fail(nullptr, TAMF_ERR_INVALID, "unknown model kind");
   if (max_batch <= 0 || max_frames <= 0 || max_frames > 4990) return fail(nullptr, TAMF_ERR_INVALID, "bad max_batch/max_frames");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(nullptr, TAMF_ERR_HIP, "no HIP device visible: libtamf_hip has no CPU fallback");
+  hipError_t de = hipGetDeviceCount(&ndev);
+  if (de != hipSuccess || ndev <= 0)
+    return fail(nullptr, TAMF_ERR_HIP, std::string("no HIP device visible (") + hipGetErrorString(de) +
+                                           "): libtamf_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(nullptr, TAMF_ERR_INVALID, "device index out of range");
 
   tamf_ctx* ctx = new tamf_ctx();
@@ -598,23 +605,36 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   typedef typename Op::elem_t E;
   const int d = ctx->d, ff = ctx->ff, B = ctx->B, T = ctx->T, S = ctx->S, Sp = ctx->Sp, M = ctx->M, P = ctx->P;
   int nk = 0;
+  // algorithmic FLOPs of the reference work each launch stands for (true S, not padded rows)
+  const double BS = (double)B * S, BT = (double)B * T, dd = d, F = ctx->F;
+  auto mark = [&](const char* name, double flops) {
+    ++nk;
+    if (!ctx->prof_on) return;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    (void)hipEventRecord(ev, st);
+    ctx->prof_ev.push_back(ev);
+    ctx->prof_names.push_back(name);
+    ctx->prof_flops.push_back(flops);
+  };
   {
     const int rows = P + (Sp - S);
     hipLaunchKernelGGL((prefix_fill_kernel<Op>), grid1d((long)B * rows * (d / 8)), dim3(256), 0, st, ctx->X, (E*)ctx->X_op.p,
                        ctx->X_op.ps, ctx->temb, ctx->tcur, ctx->pstatic, B, d, P, ctx->has_t, S, Sp);
-    ++nk;
+    mark("prefix_fill", ctx->has_t ? B * 4.0 * dd * dd : 0.0);
   }
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
     GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->xs_op.ps, ctx->XK, (const E*)ctx->Wfused.p, ctx->Wfused.ps, ctx->XK, B * T, d, ctx->XK};
     EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, ctx->h1_op.ps, d, ACT_SILU};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-    ++nk;
+    mark("gemm_input_merge0", BT * (2.0 * F * dd + 2.0 * dd * (ctx->arch.kind == TAMF_KIND_R ? 3 : 2) * dd +
+                                    (ctx->arch.kind == TAMF_KIND_R ? 2.0 * ctx->arch.h2o_dim * dd : 0.0)));
   }
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, ctx->h1_op.ps, d, (const E*)ctx->Wm2.p, ctx->Wm2.ps, d, B * T, d, d};
     EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, d, T, Sp, P};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-    ++nk;
+    mark("gemm_input_merge2", BT * 2.0 * dd * dd);
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
   for (int l = 0; l < ctx->L; ++l) {
@@ -623,36 +643,36 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.Win.p, w.Win.ps, d, M, 3 * d, d};
       EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, ctx->QK_op.ps, (E*)ctx->Vt_op.p, ctx->Vt_op.ps, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-      ++nk;
+      mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
       AttnArgs<Op> aa{(const E*)ctx->QK_op.p, ctx->QK_op.ps, (const E*)ctx->Vt_op.p, ctx->Vt_op.ps, (E*)ctx->A_op.p, ctx->A_op.ps, S, Sp, ctx->Skp, d, ctx->H};
       HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
-      ++nk;
+      mark("attention", 4.0 * B * (double)S * S * dd);
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, ctx->A_op.ps, d, (const E*)w.Wout.p, w.Wout.ps, d, M, d, d};
       EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
-      ++nk;
+      mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.W1.p, w.W1.ps, d, M, ff, d};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ctx->H_op.ps, ff, ACT_GELU};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-      ++nk;
+      mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ctx->H_op.ps, ff, (const E*)w.W2.p, w.W2.ps, ff, M, d, ff};
       EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
-      ++nk;
+      mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
     }
   }
   {
     GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)ctx->Wf.p, ctx->Wf.ps, d, M, ctx->XN, d};
     HIPCHK(ctx, gemm128<Op>(ga, head_in, st));
-    ++nk;
+    mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
   ctx->step_kernels = nk;
   return 0;
@@ -807,6 +827,56 @@ extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t 
 }
 
 extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
+
+template <class Op>
+static int profile_impl(tamf_ctx* ctx, hipStream_t st) {
+  EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
+  h.seed = 1;
+  return enqueue_step<Op>(ctx, st, h);
+}
+
+extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host,
+                                 void* stream) {
+  if (!ctx || !ms_host || !flops_host || !names_host || max_n <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  if (!ctx->cond_set || ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "conditioning / schedule not set");
+  if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "needs a G context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->prof_ev.clear();
+  ctx->prof_names.clear();
+  ctx->prof_flops.clear();
+  hipEvent_t ev0;
+  HIPCHK(ctx, hipEventCreate(&ev0));
+  ctx->prof_on = true;
+  int rc;
+  hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B);
+  (void)hipEventRecord(ev0, st);
+  switch (ctx->prec) {
+    case TAMF_PREC_F32: rc = profile_impl<OpF32>(ctx, st); break;
+    case TAMF_PREC_BF16: rc = profile_impl<OpBF16>(ctx, st); break;
+    default: rc = profile_impl<OpBF16X3>(ctx, st); break;
+  }
+  ctx->prof_on = false;
+  hipError_t se = hipStreamSynchronize(st);
+  int n = 0;
+  if (rc == 0 && se == hipSuccess) {
+    hipEvent_t prev = ev0;
+    for (size_t i = 0; i < ctx->prof_ev.size() && n < max_n; ++i, ++n) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, prev, ctx->prof_ev[i]);
+      ms_host[n] = ms;
+      flops_host[n] = ctx->prof_flops[i];
+      snprintf(names_host + (size_t)n * 48, 48, "%s", ctx->prof_names[i].c_str());
+      prev = ctx->prof_ev[i];
+    }
+  }
+  for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ev0);
+  ctx->prof_ev.clear();
+  if (rc) return rc;
+  HIPCHK(ctx, se);
+  return n;
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernel-level test hooks

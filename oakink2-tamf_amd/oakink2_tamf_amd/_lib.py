@@ -56,6 +56,10 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is None:
             build()
+            # torch ships its own libamdhip64; import it first so that the library binds to the HIP runtime
+            # instance torch uses (one runtime per process: shared device memory, streams, contexts).
+            import torch  # noqa: F401
+
             _lib = ctypes.CDLL(LIB_PATH)
         return _lib
 
@@ -63,5 +67,5 @@ def load() -> ctypes.CDLL:
 EXPORTS = [
     "tamf_ctx_create", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
     "tamf_set_schedule", "tamf_set_cond", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
-    "tamf_step_kernel_count", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox",
+    "tamf_step_kernel_count", "tamf_step_profile", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox",
 ]

@@ -55,6 +55,7 @@ def lib() -> ctypes.CDLL:
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
         L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_step_kernel_count.argtypes = [c_void_p]
+        L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
         L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
         L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
@@ -178,7 +179,12 @@ class TamfContext:
         self.B, self.T = int(B), int(T)
 
     # -- compute ------------------------------------------------------------------------------
+    def _need_cond(self):
+        if self.B <= 0:
+            raise TamfError("conditioning not set (call set_cond first)")
+
     def denoise(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        self._need_cond()
         dev = self.device
         xd = _dev_f32(x, dev)
         assert tuple(xd.shape) == (self.B, self.input_dim, 1, self.T), (tuple(xd.shape), self.B, self.T)
@@ -203,6 +209,7 @@ class TamfContext:
     def sample_loop(self, noise: Optional[torch.Tensor] = None, seed: int = 0, clip_id_base: int = 0,
                     dump: bool = False, use_graph: bool = True, out: Optional[torch.Tensor] = None):
         """noise: (n_steps+1, B, F, 1, T) draws in reference call order, or None for device Philox."""
+        self._need_cond()
         dev = self.device
         shape = (self.B, self.input_dim, 1, self.T)
         nz = None
@@ -234,6 +241,22 @@ class TamfContext:
     @property
     def step_kernel_count(self) -> int:
         return int(lib().tamf_step_kernel_count(self._h))
+
+    def step_profile(self, max_n: int = 256):
+        """[(name, ms, algorithmic_flops)] of one denoiser step, measured with HIP events on the launch stream."""
+        self._need_cond()
+        ms = (c_float * max_n)()
+        fl = (c_double * max_n)()
+        names = ctypes.create_string_buffer(max_n * 48)
+        with torch.cuda.device(self.device):
+            n = lib().tamf_step_profile(self._h, max_n, ms, fl, names, c_void_p(_stream_ptr(self.device)))
+        if n < 0:
+            _check(n, self._h)
+        out = []
+        for i in range(n):
+            nm = names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
+            out.append((nm, float(ms[i]), float(fl[i])))
+        return out
 
 
 # ---- kernel-level test hooks ---------------------------------------------------------------------
