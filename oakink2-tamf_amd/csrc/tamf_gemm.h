@@ -404,20 +404,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> 
   const char* Wb = (const char*)ga.W;
 
   int4 ra[A_PT], rw[W_PT];
-  auto gload = [&](int kt) {
-    const long ko = (long)kt * BKB;
-#pragma unroll
-    for (int i = 0; i < A_PT; ++i) ra[i] = *(const int4*)(Ab + a_goff[i] + ko);
-#pragma unroll
-    for (int i = 0; i < W_PT; ++i) rw[i] = *(const int4*)(Wb + w_goff[i] + ko);
-  };
-  auto swrite = [&](int s) {
-    char* base = smem + s * SM::STAGE;
-#pragma unroll
-    for (int i = 0; i < A_PT; ++i) *(int4*)(base + a_soff[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < W_PT; ++i) *(int4*)(base + w_soff[i]) = rw[i];
-  };
+#define TAMF_GLOAD(kt_)                                                                  \
+  {                                                                                      \
+    const long ko_ = (long)(kt_) * BKB;                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_PT; ++i) ra[i] = *(const int4*)(Ab + a_goff[i] + ko_); \
+    _Pragma("unroll") for (int i = 0; i < W_PT; ++i) rw[i] = *(const int4*)(Wb + w_goff[i] + ko_); \
+  }
+#define TAMF_SWRITE(s_)                                                                  \
+  {                                                                                      \
+    char* sb_ = smem + (s_) * SM::STAGE;                                                 \
+    _Pragma("unroll") for (int i = 0; i < A_PT; ++i) *(int4*)(sb_ + a_soff[i]) = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < W_PT; ++i) *(int4*)(sb_ + w_soff[i]) = rw[i]; \
+  }
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -429,34 +427,39 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> 
   const int a_frag = (wm0 + lr) * BKB;
   const int w_frag = NP * A_BYTES + (wn0 + lr) * BKB;
 
-  gload(0);
-  swrite(0);
-  __syncthreads();
+#define TAMF_COMPUTE(s_)                                                                                       \
+  {                                                                                                            \
+    const char* cb_ = smem + (s_) * SM::STAGE;                                                                 \
+    _Pragma("unroll") for (int kc = 0; kc < BKB / 64; ++kc) {                                                  \
+      const int coff = (((kc * 4 + g) ^ sw) << 4);                                                             \
+      int4 af[MI][NP];                                                                                         \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int p = 0; p < NP; ++p)         \
+          af[mi][p] = *(const int4*)(cb_ + p * A_BYTES + a_frag + mi * 16 * BKB + coff);                       \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                      \
+        int4 wf[NP];                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                         \
+            wf[p] = *(const int4*)(cb_ + p * W_BYTES + w_frag + ni * 16 * BKB + coff);                         \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf, af[mi]);                    \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
 
-  for (int kt = 0; kt < KT; ++kt) {
+  TAMF_GLOAD(0)
+  TAMF_SWRITE(0)
+  __syncthreads();
+  // steady state: fetch tile kt+1 into registers while tile kt is multiplied out of LDS
+  for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
-    const char* base = smem + cur * SM::STAGE;
-#pragma unroll
-    for (int kc = 0; kc < BKB / 64; ++kc) {
-      const int coff = (((kc * 4 + g) ^ sw) << 4);
-      int4 af[MI][NP];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) af[mi][p] = *(const int4*)(base + p * A_BYTES + a_frag + mi * 16 * BKB + coff);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int4 wf[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) wf[p] = *(const int4*)(base + p * W_BYTES + w_frag + ni * 16 * BKB + coff);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf, af[mi]);  // D rows = n (4g+reg), cols = m (lr)
-      }
-    }
-    if (kt + 1 < KT) swrite(cur ^ 1);
+    TAMF_GLOAD(kt + 1)
+    TAMF_COMPUTE(cur)  // D rows = n (4g+reg), cols = m (lr)
+    TAMF_SWRITE(cur ^ 1)
     __syncthreads();
   }
+  TAMF_COMPUTE((KT - 1) & 1)
+  __syncthreads();
+#undef TAMF_GLOAD
+#undef TAMF_SWRITE
+#undef TAMF_COMPUTE
 
   // park the accumulators in the LDS C tile: lane (g, lr) holds C[m = lr][n = 4g .. 4g+3] of each 16x16 tile
   float* Ct = (float*)smem;
