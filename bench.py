@@ -40,6 +40,20 @@ def flops_per_clip_step(arch, T):
     return L * S * (8 * d * d + 4 * d * ff + 4 * S * d) + T * (4 * 99 * d + 6 * d * d) + 4 * d * d
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-CPU quota; oversubscribing it is 20x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(arch_name, T, n_ddpm, sample_B=16, timed=2):
     """The oracle (torch-CPU restatement of the reference, proven equal to it on tests/golden) timed on the host
     cores: a bounded sample of the same workload - `sample_B` clips x (1 warm-up + `timed`) denoiser+DDPM steps -
@@ -49,7 +63,7 @@ def cpu_baseline(arch_name, T, n_ddpm, sample_B=16, timed=2):
     from oracle import mdm_oracle as O
 
     arch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[arch_name]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = O.det_state_dict(arch, tag="bench/w")
     cond = O.det_cond(sample_B, T, tag="bench/c", arch=arch)

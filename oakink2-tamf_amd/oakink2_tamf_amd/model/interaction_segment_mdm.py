@@ -1,0 +1,259 @@
+"""InterationSegmentMDM - the MF-MDM "G" denoiser behind the reference's module interface
+(reference model/interaction_segment_mdm.py:12-174), computed by the gfx950 HIP library.
+
+Same constructor keywords, same parameter / buffer names (so the reference's checkpoints load with
+load_state_dict, launch/sample.py:190-192) and the same call contract `model(x, timesteps, batch=...)`
+(x: (B, input_dim, 1, T) float32, timesteps: (B,) int64, returns x0_hat of x's shape).  The module is only a
+parameter container plus a thin dispatcher: forward() hands the tensors to libtamf_hip (hip_backend.TamfContext);
+there is no PyTorch compute path and no CPU fallback.
+
+Differences from the reference, all deliberate:
+  * the frozen CLIP text tower is not re-run inside every forward (the reference does, :145); pass its output as
+    batch["text_embedding"] (B, clip_dim) float32 - or construct with load_clip=True (needs the `clip` package)
+    and pass batch["text"], in which case it is encoded once per distinct batch dict;
+  * step-invariant conditioning (prefix tokens 1..4, object half of input_merge.0) is computed once per batch dict;
+  * eval only (dropout is identity in the reference's eval mode; autograd is not supported);
+  * train()/eval() return self (the reference's override returns None, :176-178).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_logger = logging.getLogger(__name__)
+
+
+class PositionalEncoding(nn.Module):
+    """sin/cos table buffer `pe` (max_len, 1, d) - reference :181-198 (only the buffer is used here)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1).contiguous())
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, latent_dim, sequence_pos_encoder):
+        super().__init__()
+        self.sequence_pos_encoder = sequence_pos_encoder
+        self.time_embed = nn.Sequential(nn.Linear(latent_dim, latent_dim), nn.SiLU(), nn.Linear(latent_dim, latent_dim))
+
+
+class _Linear(nn.Module):
+    def __init__(self, attr, in_f, out_f):
+        super().__init__()
+        setattr(self, attr, nn.Linear(in_f, out_f))
+
+
+class HandsideProcess(nn.Module):
+    def __init__(self, latent_dim):
+        super().__init__()
+        self.register_buffer("rh_embed", torch.zeros(latent_dim))
+        lh = torch.zeros(latent_dim)
+        lh[0] = 1.0
+        self.register_buffer("lh_embed", lh)
+
+
+class _HipDenoiserBase(nn.Module):
+    """Shared HIP plumbing of the G and R modules."""
+
+    kind = "G"
+    supports_fused_loop = False
+
+    def _init_hip(self, arch: Dict[str, int], precision: str, max_batch: Optional[int], max_frames: Optional[int]):
+        self._arch = dict(arch)
+        self.precision = precision
+        self._max_batch, self._max_frames = max_batch, max_frames
+        self._ctx = None
+        self._ctx_dirty = True
+        self._cond_key = None
+        self._sched_key = None
+        self._max_timesteps = 1000
+
+    # weights changed -> re-upload lazily
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._ctx_dirty = True
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._ctx_dirty = True
+        return out
+
+    def refresh_hip_weights(self):
+        """Call after modifying parameters in place."""
+        self._ctx_dirty = True
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _context(self, B: int, T: int):
+        from ..hip_backend import TamfContext, require_gpu
+
+        dev = require_gpu(self._device())
+        need_new = (self._ctx is None or self._ctx_dirty or B > self._ctx.max_batch or T > self._ctx.max_frames
+                    or self._ctx.device != dev)
+        if need_new:
+            if self._ctx is not None:
+                self._ctx.close()
+            mb = max(B, self._max_batch or 0)
+            mf = max(T, self._max_frames or 0)
+            self._ctx = TamfContext(self._arch, mb, mf, precision=self.precision, device=dev, kind=self.kind)
+            self._ctx.load_state_dict(self.state_dict(), max_timesteps=self._max_timesteps)
+            self._ctx_dirty = False
+            self._cond_key = None
+            self._sched_key = None
+        return self._ctx
+
+    @staticmethod
+    def _tensor_key(t):
+        return None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+
+    def _set_cond(self, ctx, batch, text_embedding):
+        key = (id(batch), tuple(batch["hand_side"]), self._tensor_key(text_embedding), self._tensor_key(batch["shape"]),
+               self._tensor_key(batch["obj_embedding"]), self._tensor_key(batch["obj_traj"]))
+        if key != self._cond_key:
+            ctx.set_cond(text_embedding, batch["hand_side"], batch["shape"], batch["obj_embedding"], batch["obj_traj"])
+            self._cond_key = key
+
+    def train(self, mode: bool = True):
+        if mode:
+            _logger.warning("the MI355X HIP denoiser is inference-only; train(True) only flips the flag")
+        return super().train(mode)
+
+
+class InterationSegmentMDM(_HipDenoiserBase):
+    kind = "G"
+    supports_fused_loop = True
+
+    def __init__(self, input_dim=99, obj_input_dim=9, hand_shape_dim=10, obj_embed_dim=768, latent_dim=256,
+                 ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu", clip_dim=512,
+                 clip_version="ViT-B/32", precision: str = "bf16x3", load_clip: bool = False,
+                 max_batch: Optional[int] = None, max_frames: Optional[int] = None, **kargs):
+        super().__init__()
+        if activation != "gelu":
+            raise NotImplementedError("the HIP FFN kernel fuses the exact erf-GELU (activation='gelu') only")
+        self.latent_dim, self.ff_size, self.num_layers, self.num_heads = latent_dim, ff_size, num_layers, num_heads
+        self.dropout, self.activation, self.clip_dim = dropout, activation, clip_dim
+        self.input_feats, self.obj_input_feats = input_dim, obj_input_dim
+        self.hand_shape_feats, self.obj_embed_feats = hand_shape_dim, obj_embed_dim
+        self.cond_mask_prob = kargs.get("cond_mask_prob", 0.0)
+        if self.cond_mask_prob:
+            raise NotImplementedError("cond_mask_prob > 0 is a training feature (never set by the launchers)")
+
+        self.hand_side_process = HandsideProcess(latent_dim)
+        self.hand_shape_process = _Linear("shape_embed", hand_shape_dim, latent_dim)
+        self.obj_embed_process = _Linear("embedding", obj_embed_dim, latent_dim)
+        self.input_process = _Linear("poseEmbedding", input_dim, latent_dim)
+        self.obj_input_process = _Linear("poseEmbedding", obj_input_dim, latent_dim)
+        self.input_merge = nn.Sequential(nn.Linear(latent_dim * 2, latent_dim), nn.SiLU(), nn.Linear(latent_dim, latent_dim))
+        self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout)
+        layer = nn.TransformerEncoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size, dropout=dropout,
+                                           activation=activation)
+        self.seqTransEncoder = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
+        self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
+        self.embed_text = nn.Linear(clip_dim, latent_dim)
+        self.output_process = _Linear("poseFinal", latent_dim, input_dim)
+        self.clip_version = clip_version
+        self.clip_model = self.load_and_freeze_clip(clip_version) if load_clip else None
+        self._text_cache = (None, None)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.eval()
+        self._init_hip(dict(input_dim=input_dim, obj_input_dim=obj_input_dim, hand_shape_dim=hand_shape_dim,
+                            obj_embed_dim=obj_embed_dim, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers,
+                            num_heads=num_heads, clip_dim=clip_dim), precision, max_batch, max_frames)
+
+    def parameters_wo_clip(self):
+        return [p for name, p in self.named_parameters() if not name.startswith("clip_model.")]
+
+    def load_and_freeze_clip(self, clip_version):
+        try:
+            import clip  # the reference's dependency (thirdparty/CLIP); optional here
+        except ImportError as e:
+            raise ImportError("load_clip=True needs the `clip` package; otherwise pass batch['text_embedding']") from e
+        clip_model, _ = clip.load(clip_version, device="cpu", jit=False)
+        clip_model.eval()
+        for p in clip_model.parameters():
+            p.requires_grad = False
+        return clip_model
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        # checkpoints never contain the CLIP tower (util/state_util.py:32-34)
+        return type(sd)((k, v) for k, v in sd.items() if not k.startswith("clip_model."))
+
+    def encode_text(self, raw_text):
+        """CLIP text features (B, clip_dim) float32 - reference :111-132 (context 20+2, zero-padded to 77)."""
+        if self.clip_model is None:
+            raise KeyError("batch['text_embedding'] missing and no CLIP tower loaded (construct with load_clip=True)")
+        import clip
+
+        dev = self._device()
+        texts = clip.tokenize(raw_text, context_length=22, truncate=True).to(dev)
+        texts = torch.cat([texts, torch.zeros([texts.shape[0], 77 - 22], dtype=texts.dtype, device=dev)], dim=1)
+        return self.clip_model.encode_text(texts).float()
+
+    def _text_embedding(self, batch):
+        if "text_embedding" in batch and batch["text_embedding"] is not None:
+            return batch["text_embedding"]
+        key = (id(batch), tuple(batch["text"]))
+        if self._text_cache[0] != key:
+            with torch.no_grad():
+                self._text_cache = (key, self.encode_text(batch["text"]))
+        return self._text_cache[1]
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, batch):
+        """x: (B, input_dim, 1, T); timesteps: (B,) int; batch: dict with "text_embedding" (or "text"),
+        "hand_side", "shape", "obj_embedding", "obj_traj"  ->  x0_hat (B, input_dim, 1, T)."""
+        B, _, _, T = x.shape
+        ctx = self._context(B, T)
+        self._set_cond(ctx, batch, self._text_embedding(batch))
+        return ctx.denoise(x, timesteps)
+
+    @torch.no_grad()
+    def fused_sample_loop(self, diffusion, shape, x_T=None, batch=None, dump_steps=None, noise_source="philox",
+                          seed=None, clip_id_base=0, device=None):
+        """The whole p_sample_loop as one library call (hipGraph replay); see GaussianDiffusion.p_sample_loop."""
+        B, F, _, T = shape
+        N = diffusion.num_timesteps
+        self._max_timesteps = max(self._max_timesteps, N)
+        ctx = self._context(B, T)
+        skey = (id(diffusion), N)
+        if self._sched_key != skey:
+            ctx.set_schedule(diffusion.posterior_mean_coef1, diffusion.posterior_mean_coef2,
+                             diffusion.posterior_log_variance_clipped)
+            self._sched_key = skey
+        self._set_cond(ctx, batch, self._text_embedding(batch))
+        dev = ctx.device
+        noise = None
+        if noise_source in ("torch", "torch_cpu") or x_T is not None:
+            gen_dev = torch.device("cpu") if noise_source == "torch_cpu" else dev
+            n_bytes = (N + 1) * B * F * T * 4
+            if n_bytes > 8 << 30:
+                raise MemoryError(f"pre-drawn noise would need {n_bytes / 2**30:.1f} GiB; use noise_source='philox'")
+            draws = torch.empty((N + 1, B, F, 1, T), dtype=torch.float32, device=dev)
+            if noise_source == "philox":  # explicit x_T + device Philox for the step noise is not expressible: draw on device
+                noise_source = "torch"
+                gen_dev = dev
+            draws[0] = x_T.to(dev) if x_T is not None else torch.randn(*shape, device=gen_dev).to(dev)
+            for k in range(1, N + 1):  # th.randn_like(x) once per step, reference :448
+                draws[k] = torch.randn(*shape, device=gen_dev).to(dev)
+            noise = draws
+        if seed is None:
+            seed = torch.initial_seed()
+        res = ctx.sample_loop(noise=noise, seed=seed, clip_id_base=clip_id_base, dump=dump_steps is not None)
+        if dump_steps is not None:
+            out, dump = res
+            return [dump[i].clone() for i in range(N) if i in dump_steps]
+        return res

@@ -217,6 +217,58 @@ def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_nois
     np.savez_compressed(os.path.join(OUT_DIR, f"loop_{name}.npz"), **fix)
 
 
+def capture_refine(name: str, arch: O.Arch, B: int, T: int, nobj=2):
+    """R trunk (segment_refine_model.py:175-217) with the external pieces stubbed as SURVEY.md 8c prescribes:
+    manotorch.ManoLayer / pytorch3d.Meshes are stand-in modules, MANO recovery returns zeros and the
+    hand->object distance is the supplied tensor, so refine_pose_repr pins exactly the trunk."""
+    mt = types.ModuleType("manotorch")
+    mtl = types.ModuleType("manotorch.manolayer")
+
+    class ManoLayer(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.register_buffer("th_faces", torch.zeros(1538, 3, dtype=torch.long))
+
+    mtl.ManoLayer = ManoLayer
+    mt.manolayer = mtl
+    p3 = types.ModuleType("pytorch3d")
+    p3s = types.ModuleType("pytorch3d.structures")
+    p3s.Meshes = object
+    p3.structures = p3s
+    for k, v in (("manotorch", mt), ("manotorch.manolayer", mtl), ("pytorch3d", p3), ("pytorch3d.structures", p3s)):
+        sys.modules.setdefault(k, v)
+    from oakink2_tamf.model.segment_refine_model import SegmentRefineModel
+
+    h2o = torch.from_numpy(det.det_normal(f"{name}/h2o", (B, T, arch.h2o_dim))) * 0.05
+
+    class Trunk(SegmentRefineModel):
+        def batch_recover_mano_from_pose_repr(self, pose_repr, shape, hand_side):
+            b, t = pose_repr.shape[:2]
+            return torch.zeros(b, t, 778, 3), torch.zeros(b, t, 21, 3), torch.zeros(b, t, 778, 3)
+
+        def multi_object_h2o_dist(self, *a, **k):
+            return h2o
+
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    m = Trunk(None, input_dim=arch.input_dim, obj_input_dim=arch.obj_input_dim, hand_shape_dim=arch.hand_shape_dim,
+              obj_embed_dim=arch.obj_embed_dim, latent_dim=arch.latent_dim, ff_size=arch.ff_size,
+              num_layers=arch.num_layers, num_heads=arch.num_heads)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("mano_layer") for k in missing), (missing, unexpected)
+    m.eval()
+    cond = O.det_cond(B, T, nobj=nobj, tag=f"{name}/c", arch=arch)
+    x_in = torch.from_numpy(det.det_normal(f"{name}/x", (B, T, arch.input_dim)))
+    batch = {"sample_pose_repr": x_in, "pose_repr": x_in, "hand_side": cond["hand_side"], "shape": cond["shape"],
+             "obj_embedding": cond["obj_embedding"], "obj_traj": cond["obj_traj"], "obj_list": None, "obj_verts": None}
+    with torch.no_grad():
+        ref = m(batch)["refine_pose_repr"]
+    mine = O.refine_forward(sd, arch, x_in, h2o, cond)
+    print(f"refine {name}: |ref-oracle32|={(ref - mine).abs().max():.3e} |ref|max={ref.abs().max():.3f}")
+    fix = {"x_in": x_in.numpy(), "h2o": h2o.numpy(), "out": ref.numpy(), "B": B, "T": T}
+    fix.update({f"cond/{k}": v for k, v in _cond_np(cond).items() if k != "text_embedding"})
+    np.savez_compressed(os.path.join(OUT_DIR, f"refine_{name}.npz"), **fix)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -236,6 +288,8 @@ def main():
     capture_loop("arch_mdm_b4_t64_50", O.ARCH_MDM, B=4, T=64, steps=50, store_noise=False)
     # full-length loop on the tiny arch
     capture_loop("tiny_1000", O.ARCH_TINY, B=2, T=16, steps=1000, store_noise=False)
+    capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
+    capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
 
 
 if __name__ == "__main__":
