@@ -22,6 +22,7 @@ struct GemmArgs {
   long w_ps;
   int ldw;
   int M, N, K;
+  int krot;  // != 0: workgroup b starts its K loop at tile (b * krot) % KT (spreads concurrent reads of shared tiles over L2 channels)
 };
 
 template <class Op, int BM, int BN, int BKB>
@@ -89,8 +90,13 @@ struct EpiBiasAct {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
       } else if (act == ACT_GELU) {
+        if constexpr (OutOp::PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
+        }
       }
       OutOp::template store<8>(out, out_ps, (long)gr * ldo + gn, v);
     }
@@ -355,8 +361,16 @@ struct EpiStoreF32 {
 // ------------------------------------------------------------------------------------------------
 // The kernel
 // ------------------------------------------------------------------------------------------------
+// waves per SIMD the kernel is built for: LDS admits 2 workgroups per CU for the 128x128 tiles, 1 for the 64xN ones;
+// telling the compiler keeps its occupancy heuristics from spilling / sinking the prefetch registers
+template <class Op, int BM, int BN, int BKB, int NWV = 4>
+struct GemmOcc {
+  static constexpr int WG_PER_CU = (GemmSmem<Op, BM, BN, BKB>::BYTES > 80 * 1024) ? 1 : 2;
+  static constexpr int WAVES_PER_SIMD = WG_PER_CU * NWV / 4;
+};
+
 template <class Op, int BM, int BN, int WGM, int WGN, int BKB, class Epi>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> ga, const Epi epi) {
+__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB>::WAVES_PER_SIMD)) void gemm_kernel(const GemmArgs<Op> ga, const Epi epi) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int NP = Op::NP;
   constexpr int CPR = BKB / 16;  // 16-byte chunks per tile row
@@ -444,13 +458,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> 
     }                                                                                                          \
   }
 
-  TAMF_GLOAD(0)
+  const int rot = ga.krot ? (int)(((unsigned)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)ga.krot) % (unsigned)KT) : 0;
+  TAMF_GLOAD(rot)
   TAMF_SWRITE(0)
   __syncthreads();
   // steady state: fetch tile kt+1 into registers while tile kt is multiplied out of LDS
   for (int kt = 0; kt < KT - 1; ++kt) {
     const int cur = kt & 1;
-    TAMF_GLOAD(kt + 1)
+    int ktn = kt + 1 + rot;
+    ktn = ktn >= KT ? ktn - KT : ktn;
+    TAMF_GLOAD(ktn)
+    // NOTE: hipcc sinks these prefetch loads towards the LDS stores below (shorter live ranges); pinning them with
+    // sched_barrier(0) makes it keep the staging arrays in scratch instead (2x slower).  v2 (LDS-DMA) avoids both.
     TAMF_COMPUTE(cur)  // D rows = n (4g+reg), cols = m (lr)
     TAMF_SWRITE(cur ^ 1)
     __syncthreads();
@@ -471,5 +490,194 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmArgs<Op> 
       *(float4*)(Ct + (wm0 + mi * 16 + lr) * SM::LDC + wn0 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
     }
   __syncthreads();
+  epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-DMA staging.  Tiles go global -> LDS directly (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KiB
+// "piece" per wave-instruction, LDS destination = wave-uniform base + 16*lane), so there is no register staging
+// and no ds_write pass.  The LDS image is the same swizzled image as v1: because the DMA writes linearly, the
+// swizzle is applied to each lane's SOURCE address (lane -> (row, physical chunk) -> logical chunk = physical ^
+// swz(row)).  Tile k+1's pieces are issued interleaved with tile k's MFMA groups; one __syncthreads() per K tile
+// (it waits vmcnt(0) for the wave's own pieces, the barrier covers everybody else's).
+// The workgroup id is remapped so that all N-tiles of one M-tile run on the same XCD (A row panel fetched into one
+// L2 instead of eight).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void tamf_lds_void;
+typedef const __attribute__((address_space(1))) void tamf_gbl_void;
+
+TAMF_DEV void glds16(const char* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((tamf_gbl_void*)gsrc, (tamf_lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// logical block id with XCD-contiguous chunks (bijective for any grid size; blocks b and b+8 share an XCD)
+TAMF_DEV int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <class Op, int BM, int BN, int WGM, int WGN, int BKB, class Epi>
+__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel_v2(const GemmArgs<Op> ga, const Epi epi) {
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int NWV = WGM * WGN;
+  constexpr int NP = Op::NP;
+  constexpr int CPR = BKB / 16;    // 16-byte chunks per tile row
+  constexpr int RPI = 1024 / BKB;  // tile rows per 1-KiB piece
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int A_PIECES = NP * BM / RPI, W_PIECES = NP * BN / RPI;
+  constexpr int A_PW = A_PIECES / NWV, W_PW = W_PIECES / NWV;
+  static_assert(A_PIECES % NWV == 0 && W_PIECES % NWV == 0, "pieces must divide over the waves");
+  typedef GemmSmem<Op, BM, BN, BKB> SM;
+  constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB;
+  constexpr int KCN = BKB / 64;
+  constexpr int TOT_PW = A_PW + W_PW;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int ntn = ga.N / BN;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (lb % ntn) * BN, m0 = (lb / ntn) * BM;
+  const int M = ga.M;
+  const int KT = (ga.K * Op::EB) / BKB;
+
+  // per-piece source byte offsets of this lane (k-tile term added at issue time) and wave-uniform LDS offsets
+  unsigned a_off[A_PW], w_off[W_PW];
+  const int prow = lane / CPR, pch = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < A_PW; ++i) {
+    const int q = wave + i * NWV;
+    const int p = q / (BM / RPI), jr = q % (BM / RPI);
+    const int row = jr * RPI + prow;
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    a_off[i] = (unsigned)(((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < W_PW; ++i) {
+    const int q = wave + i * NWV;
+    const int p = q / (BN / RPI), jr = q % (BN / RPI);
+    const int row = jr * RPI + prow;
+    w_off[i] = (unsigned)(((long)p * ga.w_ps + (long)(n0 + row) * ga.ldw) * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
+  }
+  const char* Ab = (const char*)ga.A;
+  const char* Wb = (const char*)ga.W;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = swz_chunk<BKB>(lr);
+  const int a_frag = (wm0 + lr) * BKB;
+  const int w_frag = NP * A_BYTES + (wn0 + lr) * BKB;
+
+  // prologue: tile 0
+#define TAMF_ISSUE_ALL(kt_, s_)                                                       \
+  {                                                                                   \
+    _Pragma("unroll") for (int ii = 0; ii < TOT_PW; ++ii) {                           \
+      if (ii < A_PW) {                                                                \
+        const int pq_ = wave + ii * NWV;                                              \
+        glds16(Ab + a_off[ii < A_PW ? ii : 0] + (long)(kt_) * BKB,                    \
+               smem + (s_) * SM::STAGE + (pq_ / (BM / RPI)) * A_BYTES + (pq_ % (BM / RPI)) * 1024); \
+      } else {                                                                        \
+        const int pq_ = wave + (ii - A_PW) * NWV;                                     \
+        glds16(Wb + w_off[ii >= A_PW ? ii - A_PW : 0] + (long)(kt_) * BKB,            \
+               smem + (s_) * SM::STAGE + NP * A_BYTES + (pq_ / (BN / RPI)) * W_BYTES + (pq_ % (BN / RPI)) * 1024); \
+      }                                                                               \
+    }                                                                                 \
+  }
+  // L2 prefetch by touch: waves 0..3 each issue ONE sparse dword load (L1-bypassing, sc1) per K tile that pulls the
+  // lines of tile kt+PF into the XCD's L2, so the LDS-DMA of that tile later sees L2-hit instead of MALL/HBM latency.
+  // No LDS is needed for this extra prefetch depth.  Rows touched by this workgroup: all of its own A rows (waves
+  // 0,1) and a 1/8 slice of the W rows (waves 2,3) - the ~26 workgroups sharing the XCD cover the other slices.
+  const int pf = (ga.krot >> 8) & 0xF;
+  const char* tbase = nullptr;   // per-lane touch address for tile 0 (null: this lane does not touch)
+  {
+    const int peer = (blockIdx.x >> 3) & 7;
+    if (wave < 2) {
+      const int r = wave * 64 + lane;  // A row slot: plane-major
+      if (r < NP * BM) {
+        const int p = r / BM;
+        int gr = m0 + r % BM;
+        gr = gr < M ? gr : M - 1;
+        tbase = Ab + ((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB;
+      }
+    } else if (wave < 4) {
+      constexpr int WSL = NP * BN / 8;  // W row slots of this workgroup's slice
+      const int j = (wave - 2) * 64 + lane;
+      if (j < WSL) {
+        const int r = peer * WSL + j;
+        const int p = r / BN;
+        tbase = Wb + ((long)p * ga.w_ps + (long)(n0 + r % BN) * ga.ldw) * Op::EB;
+      }
+    }
+  }
+  unsigned tsink = 0;
+
+  // krot: bits 0-7 = rotation stride; bits 8-11 = L2 touch-prefetch distance in K tiles (0 = off);
+  // bit 12 = ablation "no loads after tile 0"; bit 13 = ablation "no compute"
+  const int krs = ga.krot & 0xFF;
+  const bool abl_noload = (ga.krot & 0x1000) != 0, abl_nocomp = (ga.krot & 0x2000) != 0;
+  const int rot = krs ? (int)(((unsigned)lb * (unsigned)krs) % (unsigned)KT) : 0;
+  TAMF_ISSUE_ALL(rot, 0)
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < KT) && !abl_noload;
+    int ktn = kt + 1 + rot;
+    ktn = ktn >= KT ? ktn - KT : ktn;
+    const char* cb = smem + cur * SM::STAGE;
+    // next tile's pieces first: their latency is covered by this tile's MFMAs (waited for at the barrier below)
+    unsigned tv = 0;
+    if (pf && tbase && kt + pf < KT) {
+      int ktp = kt + pf + rot;
+      ktp = ktp >= KT ? ktp - KT : ktp;
+      tv = __hip_atomic_load((const unsigned*)(tbase + (long)ktp * BKB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (more) TAMF_ISSUE_ALL(ktn, cur ^ 1)
+    if (!abl_nocomp) {
+#pragma unroll
+      for (int kc = 0; kc < KCN; ++kc) {
+        const int coff = (((kc * 4 + g) ^ sw) << 4);
+        // all fragments of the K chunk are requested up front, so LDS latency is paid once per chunk and the
+        // MFMAs stream behind counted lgkmcnt waits
+        int4 af[MI][NP], wf[NI][NP];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) af[mi][p] = *(const int4*)(cb + p * A_BYTES + a_frag + mi * 16 * BKB + coff);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) wf[ni][p] = *(const int4*)(cb + p * W_BYTES + w_frag + ni * 16 * BKB + coff);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);
+      }
+    }
+    __syncthreads();
+    tsink ^= tv;  // consumed after the barrier's vmcnt(0): keeps the touch load alive without an extra wait
+  }
+#undef TAMF_ISSUE_ALL
+
+  float* Ct = (float*)smem;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const f32x4 v = acc[mi][ni];
+      *(float4*)(Ct + (wm0 + mi * 16 + lr) * SM::LDC + wn0 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  __syncthreads();
+  if (tsink == 0x9E3779B9u && ga.M < 0) Ct[0] = 1.0f;  // never true; keeps the touch loads from being optimised away
   epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
 }

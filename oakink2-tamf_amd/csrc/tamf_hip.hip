@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -167,14 +168,32 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // ------------------------------------------------------------------------------------------------
 // kernel launchers
 // ------------------------------------------------------------------------------------------------
+// K-loop rotation stride per workgroup (0 = off).  TAMF_GEMM_KROT overrides.
+static int g_krot = []() {
+  const char* e = getenv("TAMF_GEMM_KROT");
+  return e ? atoi(e) : 0;
+}();
+
+// kernel variant: 1 = register-staged (v1), 2 = LDS-DMA staged + XCD-aware tile order (v2).  TAMF_GEMM_VARIANT overrides.
+static int g_gemm_variant = []() {
+  const char* e = getenv("TAMF_GEMM_VARIANT");
+  return e ? atoi(e) : 2;
+}();
+
 template <class Op, int BM, int BN, int BKB, class Epi>
 struct GemmLaunch {
   static constexpr int SMEM = GemmSmem<Op, BM, BN, BKB>::BYTES;
+  // v2 wave grid: the 64-row LayerNorm tiles run 8 waves (2 x 4) so that two waves share each SIMD and cover each
+  // other's LDS / barrier latency; the 128 x 128 tiles run 4 waves (2 x 2) with two workgroups per CU
+  static constexpr int V2_WGN = (BM == 64) ? 4 : 2;
   static hipError_t prepare() {
     static bool done = false;
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_kernel_v2<Op, BM, BN, 2, V2_WGN, BKB, Epi>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e == hipSuccess) done = true;
     return e;
   }
@@ -182,8 +201,12 @@ struct GemmLaunch {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
     if ((ga.K * Op::EB) % BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
-    dim3 grid(ga.N / BN, (ga.M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>), grid, dim3(256), SMEM, st, ga, epi);
+    const int ntn = ga.N / BN, ntm = (ga.M + BM - 1) / BM;
+    if (g_gemm_variant == 1) {
+      hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>), dim3(ntn, ntm), dim3(256), SMEM, st, ga, epi);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel_v2<Op, BM, BN, 2, V2_WGN, BKB, Epi>), dim3(ntn * ntm), dim3(2 * V2_WGN * 64), SMEM, st, ga, epi);
+    }
     return hipGetLastError();
   }
 };
@@ -502,10 +525,10 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     float* tmp = nullptr;
     TRY(dev_alloc(ctx, (void**)&ctx->temb, (size_t)ctx->n_t * d * 4));
     TRY(dev_alloc(ctx, (void**)&tmp, (size_t)ctx->n_t * d * 4));
-    GemmArgs<OpF32> g1{ctx->pe, 0, d, (const float*)ctx->Wt1_f32.p, 0, d, ctx->n_t, d, d};
+    GemmArgs<OpF32> g1{ctx->pe, 0, d, (const float*)ctx->Wt1_f32.p, 0, d, ctx->n_t, d, d, g_krot};
     EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, 0, d, ACT_SILU};
     HIPCHK(ctx, gemm128<OpF32>(g1, e1, st));
-    GemmArgs<OpF32> g2{tmp, 0, d, (const float*)ctx->Wt2_f32.p, 0, d, ctx->n_t, d, d};
+    GemmArgs<OpF32> g2{tmp, 0, d, (const float*)ctx->Wt2_f32.p, 0, d, ctx->n_t, d, d, g_krot};
     EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, 0, d, 0x7FFFFFFF, 0, 0};
     HIPCHK(ctx, gemm128<OpF32>(g2, e2, st));
   }
@@ -589,7 +612,7 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
   hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd);
   hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * T * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wq, ctx->bq,
                      ctx->objfeat, (long)B * T, d, qd);
-  GemmArgs<OpF32> ga{ctx->objfeat, 0, d, (const float*)ctx->Wm1b_f32.p, 0, d, B * T, d, d};
+  GemmArgs<OpF32> ga{ctx->objfeat, 0, d, (const float*)ctx->Wm1b_f32.p, 0, d, B * T, d, d, g_krot};
   EpiBiasAct<OpF32> ep{ctx->cbias, nullptr, 0, ctx->cobj, 0, d, ACT_NONE};
   HIPCHK(ctx, gemm128<OpF32>(ga, ep, st));
   HIPCHK(ctx, hipGetLastError());
@@ -624,14 +647,14 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     mark("prefix_fill", ctx->has_t ? B * 4.0 * dd * dd : 0.0);
   }
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
-    GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->xs_op.ps, ctx->XK, (const E*)ctx->Wfused.p, ctx->Wfused.ps, ctx->XK, B * T, d, ctx->XK};
+    GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->xs_op.ps, ctx->XK, (const E*)ctx->Wfused.p, ctx->Wfused.ps, ctx->XK, B * T, d, ctx->XK, g_krot};
     EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, ctx->h1_op.ps, d, ACT_SILU};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge0", BT * (2.0 * F * dd + 2.0 * dd * (ctx->arch.kind == TAMF_KIND_R ? 3 : 2) * dd +
                                     (ctx->arch.kind == TAMF_KIND_R ? 2.0 * ctx->arch.h2o_dim * dd : 0.0)));
   }
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
-    GemmArgs<Op> ga{(const E*)ctx->h1_op.p, ctx->h1_op.ps, d, (const E*)ctx->Wm2.p, ctx->Wm2.ps, d, B * T, d, d};
+    GemmArgs<Op> ga{(const E*)ctx->h1_op.p, ctx->h1_op.ps, d, (const E*)ctx->Wm2.p, ctx->Wm2.ps, d, B * T, d, d, g_krot};
     EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, d, T, Sp, P};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd);
@@ -640,7 +663,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   for (int l = 0; l < ctx->L; ++l) {
     const LayerW& w = ctx->layers[l];
     {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.Win.p, w.Win.ps, d, M, 3 * d, d};
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.Win.p, w.Win.ps, d, M, 3 * d, d, g_krot};
       EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, ctx->QK_op.ps, (E*)ctx->Vt_op.p, ctx->Vt_op.ps, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
@@ -651,26 +674,26 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       mark("attention", 4.0 * B * (double)S * S * dd);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->A_op.p, ctx->A_op.ps, d, (const E*)w.Wout.p, w.Wout.ps, d, M, d, d};
+      GemmArgs<Op> ga{(const E*)ctx->A_op.p, ctx->A_op.ps, d, (const E*)w.Wout.p, w.Wout.ps, d, M, d, d, g_krot};
       EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
       mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.W1.p, w.W1.ps, d, M, ff, d};
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.W1.p, w.W1.ps, d, M, ff, d, g_krot};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ctx->H_op.ps, ff, ACT_GELU};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ctx->H_op.ps, ff, (const E*)w.W2.p, w.W2.ps, ff, M, d, ff};
+      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ctx->H_op.ps, ff, (const E*)w.W2.p, w.W2.ps, ff, M, d, ff, g_krot};
       EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
       mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
     }
   }
   {
-    GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)ctx->Wf.p, ctx->Wf.ps, d, M, ctx->XN, d};
+    GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)ctx->Wf.p, ctx->Wf.ps, d, M, ctx->XN, d, g_krot};
     HIPCHK(ctx, gemm128<Op>(ga, head_in, st));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
@@ -907,7 +930,7 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   if (!ao || !wo || !yo) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
   hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)M * (Kp / 8)), dim3(256), 0, st, a, ao, (long)M * Kp, (long)M, K, Kp);
   hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)N * (Kp / 8)), dim3(256), 0, st, w, wo, (long)N * Kp, (long)N, K, Kp);
-  GemmArgs<Op> ga{ao, (long)M * Kp, Kp, wo, (long)N * Kp, Kp, M, N, Kp};
+  GemmArgs<Op> ga{ao, (long)M * Kp, Kp, wo, (long)N * Kp, Kp, M, N, Kp, g_krot};
   hipError_t e;
   if (ln) {
     EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, (long)M * N, 1e-5f};
@@ -986,6 +1009,97 @@ extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int3
     case TAMF_PREC_BF16X3: return test_attn_impl<OpBF16X3>(B, S, H, hd, qkv_dev, out_dev, st);
     default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   }
+}
+
+// random operand fill for the kernel benchmarks (values in [-1, 1))
+template <class Op>
+__global__ void fill_operand_kernel(typename Op::elem_t* out, long ps, long n, unsigned salt) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned h = (unsigned)(i + j) * 2654435761u + salt;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    v[j] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+  }
+  Op::template store<8>(out, ps, i, v);
+}
+
+template <class Op>
+static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* ms_out, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
+  TmpBufs tb;
+  const long an = (long)M * K, wn = (long)N * K, on = (long)M * N;
+  E* a = (E*)tb.get((size_t)an * Op::NP * Op::EB);
+  E* w = (E*)tb.get((size_t)wn * Op::NP * Op::EB);
+  E* o = (E*)tb.get((size_t)on * Op::NP * Op::EB);
+  E* o2 = (E*)tb.get((size_t)on * Op::NP * Op::EB);
+  float* x = (float*)tb.get((size_t)on * 4);
+  float* vec = (float*)tb.get((size_t)N * 4 * 4);
+  if (!a || !w || !o || !o2 || !x || !vec) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(an / 8), dim3(256), 0, st, a, an, an, 1u);
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(wn / 8), dim3(256), 0, st, w, wn, wn, 2u);
+  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(on / 8), dim3(256), 0, st, x, on, on, 3u);
+  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, (long)N * 4, 4u);
+  GemmArgs<Op> ga{a, an, K, w, wn, K, M, N, K, g_krot};
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
+  hipError_t e = hipSuccess;
+  for (int it = -2; it < iters && e == hipSuccess; ++it) {
+    if (it == 0) (void)hipEventRecord(e0, st);
+    if (epi_kind == 2) {
+      EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, on, 1e-5f};
+      e = gemm_ln<Op>(ga, ep, st);
+    } else if (epi_kind == 1) {
+      const int d = N / 3;
+      EpiQKV<Op> ep{vec, o, on, o2, on, d, d / 128, 128, 208, 224, 0.1f};
+      e = gemm128<Op>(ga, ep, st);
+    } else {
+      EpiBiasAct<Op> ep{vec, nullptr, 0, o, on, N, ACT_GELU};
+      e = gemm128<Op>(ga, ep, st);
+    }
+  }
+  (void)hipEventRecord(e1, st);
+  hipError_t se = hipStreamSynchronize(st);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess || se != hipSuccess)
+    return fail(nullptr, TAMF_ERR_HIP, std::string("bench gemm: ") + hipGetErrorString(e != hipSuccess ? e : se));
+  *ms_out = ms / iters;
+  return 0;
+}
+
+extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t variant, int32_t M, int32_t N, int32_t K,
+                               int32_t iters, float* ms_out, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
+  if (epi_kind == 1 && (N % 384 || M % 208)) return fail(nullptr, TAMF_ERR_INVALID, "qkv bench needs N = 3d, M multiple of 208");
+  const int saved = g_gemm_variant, saved_rot = g_krot;
+  if (variant > 0) {  // variant = main-loop variant + 10 * krot (krot bits 12/13 = ablation flags, tamf_gemm.h)
+    g_gemm_variant = variant % 10;
+    g_krot = variant / 10;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (precision) {
+    case TAMF_PREC_F32: rc = bench_gemm_impl<OpF32>(epi_kind, M, N, K, iters, ms_out, st); break;
+    case TAMF_PREC_BF16: rc = bench_gemm_impl<OpBF16>(epi_kind, M, N, K, iters, ms_out, st); break;
+    case TAMF_PREC_BF16X3: rc = bench_gemm_impl<OpBF16X3>(epi_kind, M, N, K, iters, ms_out, st); break;
+    default: rc = fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  }
+  g_gemm_variant = saved;
+  g_krot = saved_rot;
+  return rc;
+}
+
+extern "C" int tamf_set_gemm_variant(int32_t variant) {
+  if (variant % 10 != 1 && variant % 10 != 2) return fail(nullptr, TAMF_ERR_INVALID, "variant must be 1 or 2 (+10*krot)");
+  g_gemm_variant = variant % 10;
+  g_krot = variant / 10;
+  return 0;
 }
 
 extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
