@@ -152,11 +152,12 @@ int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t 
 /* ---- kernel benchmarks / tuning (tools/kbench.py) ------------------------------------------------ */
 /* Average milliseconds of `iters` launches of one GEMM on random operands already resident in HBM.
  * epi_kind: 0 = 128x128 tile, bias + GELU (FFN1 shape); 1 = 128x128 tile, QKV epilogue (N = 3d);
- * 2 = 64xN tile, residual + LayerNorm.  variant: 0 = current default, 1 = register-staged, 2 = LDS-DMA staged. */
-int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t variant, int32_t M, int32_t N, int32_t K,
+ * 2 = 64xN tile, residual + LayerNorm.  krot: -1 = default tuning, >= 0 = GemmArgs::krot bits (csrc/tamf_gemm.h:
+ * K-loop rotation, L2 touch-prefetch distance, ablation flags). */
+int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                     int32_t iters, float* ms_out, void* stream);
-/* Select the GEMM main-loop variant used by every subsequent launch (1 or 2; default 2, env TAMF_GEMM_VARIANT). */
-int tamf_set_gemm_variant(int32_t variant);
+/* Override the GEMM tuning bits for every subsequent launch (-1 restores the per-kernel defaults). */
+int tamf_set_gemm_tuning(int32_t krot);
 
 #ifdef __cplusplus
 }

@@ -71,26 +71,33 @@ TAMF_DEV int swz_chunk(int row) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Operand traits.  A "fragment" is 16 bytes per lane per plane; one mma() consumes one 64-byte K-chunk of a
-// 16-row A tile and a 16-row B tile:  acc(16x16) += Arows . Brows^T, C layout row = 4*(lane>>4)+reg (A row),
-// col = lane & 15 (B row).
+// Operand traits.  Every operand matrix is row-major with K contiguous and is consumed in 128-byte row groups:
+//     f32     32 floats
+//     bf16    64 bf16
+//     bf16x3  32 elements as [hi: 32 bf16 | lo: 32 bf16]   (hi = bf16(x), lo = bf16(x - hi), interleaved per 64 bytes)
+// A lane (r = lane & 15, g = lane >> 4) holds two 16-byte fragments of row r of a group: f[0] = bytes [16g, 16g+16),
+// f[1] = bytes [64+16g, 64+16g+16).  mma(acc, a, b) accumulates the 16 x 16 product of a 16-row A group and a 16-row
+// B group over the group's K range: acc layout row = 4*(lane>>4)+reg (A row), col = lane & 15 (B row).
 // ---------------------------------------------------------------------------------------------
 struct OpF32 {
   typedef float elem_t;
-  static constexpr int EB = 4;  // bytes per element
-  static constexpr int NP = 1;  // operand planes
+  static constexpr int EB = 4;     // bytes per logical element inside a row
   static constexpr int PREC = 0;
-  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[1], const int4 (&b)[1]) {
-    // the 4 floats of a fragment are 4 K-steps of v_mfma_f32_16x16x4_f32 (lane group g supplies k = g);
-    // A and B use the same permuted K order, so the products pair up exactly.
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].x), as_f(b[0].x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].y), as_f(b[0].y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].z), as_f(b[0].z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[0].w), as_f(b[0].w), acc, 0, 0, 0);
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
+    // the 4 floats of a fragment are 4 K-steps of v_mfma_f32_16x16x4_f32 (lane group g supplies k = g); A and B use
+    // the same permuted K order, so the products pair up exactly (bitwise a k-ordered fp32 fma chain)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[f].x), as_f(b[f].x), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[f].y), as_f(b[f].y), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[f].z), as_f(b[f].z), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[f].w), as_f(b[f].w), acc, 0, 0, 0);
+    }
   }
+  // byte offset of logical element idx (row * ld + col; ld % 32 == 0) from the matrix base
+  static TAMF_DEV long byte_off(long idx) { return idx * 4; }
   template <int N>
-  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
-    (void)plane_stride;
+  static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     float* p = base + idx;
     if constexpr (N == 8) {
       *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
@@ -101,38 +108,44 @@ struct OpF32 {
       *(float2*)p = make_float2(v[0], v[1]);
     }
   }
+  static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = v; }
+  static TAMF_DEV float load1(const elem_t* base, long idx) { return base[idx]; }
 };
+
+template <int N>
+TAMF_DEV void store_bf16_vec(char* p, const uint32_t* w) {
+  if constexpr (N == 8) {
+    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+  } else if constexpr (N == 4) {
+    *(uint2*)p = make_uint2(w[0], w[1]);
+  } else {
+    *(uint32_t*)p = w[0];
+  }
+}
 
 struct OpBF16 {
   typedef uint16_t elem_t;
   static constexpr int EB = 2;
-  static constexpr int NP = 1;
   static constexpr int PREC = 1;
-  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[1], const int4 (&b)[1]) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]),
-                                                  acc, 0, 0, 0);
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
   }
+  static TAMF_DEV long byte_off(long idx) { return idx * 2; }
   template <int N>
-  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
-    (void)plane_stride;
+  static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t w[N / 2];
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) w[i] = f2bf(v[2 * i]) | (f2bf(v[2 * i + 1]) << 16);
-    elem_t* p = base + idx;
-    if constexpr (N == 8) {
-      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-    } else if constexpr (N == 4) {
-      *(uint2*)p = make_uint2(w[0], w[1]);
-    } else {
-      *(uint32_t*)p = w[0];
-    }
+    store_bf16_vec<N>((char*)base + idx * 2, w);
   }
+  static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = (uint16_t)f2bf(v); }
+  static TAMF_DEV float load1(const elem_t* base, long idx) { return bf2f(base[idx]); }
 };
 
 struct OpBF16X3 {
   typedef uint16_t elem_t;
-  static constexpr int EB = 2;
-  static constexpr int NP = 2;  // plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi)
+  static constexpr int EB = 4;  // hi + lo
   static constexpr int PREC = 2;
   static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
     const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), al = __builtin_bit_cast(bf16x8, a[1]);
@@ -141,8 +154,10 @@ struct OpBF16X3 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
   }
+  // element idx lives in 128-byte group idx / 32: hi at 2 * (idx % 32), lo 64 bytes further
+  static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
   template <int N>
-  static TAMF_DEV void store(elem_t* base, long plane_stride, long idx, const float* v) {
+  static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t hi[N], w[N / 2];
     float lo[N];
 #pragma unroll
@@ -152,24 +167,21 @@ struct OpBF16X3 {
     }
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) w[i] = hi[2 * i] | (hi[2 * i + 1] << 16);
-    elem_t* p = base + idx;
-    if constexpr (N == 8) {
-      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-    } else if constexpr (N == 4) {
-      *(uint2*)p = make_uint2(w[0], w[1]);
-    } else {
-      *(uint32_t*)p = w[0];
-    }
+    char* p = (char*)base + byte_off(idx);
+    store_bf16_vec<N>(p, w);
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) w[i] = f2bf(lo[2 * i]) | (f2bf(lo[2 * i + 1]) << 16);
-    p = base + plane_stride + idx;
-    if constexpr (N == 8) {
-      *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-    } else if constexpr (N == 4) {
-      *(uint2*)p = make_uint2(w[0], w[1]);
-    } else {
-      *(uint32_t*)p = w[0];
-    }
+    store_bf16_vec<N>(p + 64, w);
+  }
+  static TAMF_DEV void store1(elem_t* base, long idx, float v) {
+    char* p = (char*)base + byte_off(idx);
+    const uint32_t hi = f2bf(v);
+    *(uint16_t*)p = (uint16_t)hi;
+    *(uint16_t*)(p + 64) = (uint16_t)f2bf(v - bf2f(hi));
+  }
+  static TAMF_DEV float load1(const elem_t* base, long idx) {
+    const char* p = (const char*)base + byte_off(idx);
+    return bf2f(*(const uint16_t*)p) + bf2f(*(const uint16_t*)(p + 64));
   }
 };
 

@@ -1,34 +1,40 @@
 // LDS-staged MFMA GEMM for gfx950 with row-wise fused epilogues.
 //
-//   C[m][n] = sum_k A[m][k] * W[n][k]        A: [NP][M][lda] operand planes, W: [NP][N][ldw] operand planes
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A: [M][lda], W: [N][ldw] operand rows (K contiguous, Op::EB bytes/element)
 //
-// One 256-thread workgroup (4 waves, WGM x WGN) owns a BM x BN tile.  K is walked in tiles of BKB bytes
-// per row; tile k+1 is fetched global->registers while tile k is multiplied out of LDS (double-buffered,
-// one barrier per K tile).  LDS rows are XOR-swizzled so that both the 16-byte staging stores and the
-// ds_read_b128 fragment reads are bank-conflict free (tools/lds_bank_sim.py).  After the K loop the fp32
-// accumulators are parked in an LDS C tile (aliasing the staging buffers) and the epilogue walks it row-wise
-// with 16-byte global accesses: bias / activation / residual + LayerNorm / V-transpose / DDPM update are all
-// fused here, so every GEMM output is written to HBM exactly once, already in the operand format (bf16,
-// split bf16 or f32) of the kernel that consumes it.
+// A workgroup owns a BM x BN tile: 128 x 128 with 4 waves (2 x 2; two workgroups per CU) or 64 x d with 8 waves
+// (2 x 4; the LayerNorm-fused GEMMs need whole rows).  K is walked in tiles of 128 bytes per row - 64 bf16, 32 f32 or
+// 32 split-bf16 elements, whose hi and lo halves are interleaved at 64-byte granularity so that one tile row is one
+// full 128-byte line in every mode.  Tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1-KiB "piece" =
+// 8 rows per wave-instruction, LDS destination = wave-uniform base + 16*lane), double-buffered, one __syncthreads()
+// per K tile; the pieces of tile k+1 are issued before the MFMAs of tile k.  LDS rows are XOR-swizzled
+// (swz_chunk<128>, tools/lds_bank_sim.py) so the ds_read_b128 fragment reads are bank-conflict free; because the
+// DMA writes linearly the swizzle is applied to each lane's SOURCE address.  The workgroup id is remapped so that
+// all N-tiles of one M-tile run on the same XCD (the A panel is fetched into one L2 instead of eight).  After the K
+// loop the fp32 accumulators are parked in an LDS C tile (aliasing the staging buffers) and the epilogue walks it
+// row-wise with 16-byte global accesses: bias / activation / residual + LayerNorm / V-transpose / DDPM update are all
+// fused here, so every GEMM output is written to HBM exactly once, already in the operand format of its consumer.
 #pragma once
 #include "tamf_device.h"
 
 template <class Op>
 struct GemmArgs {
   const typename Op::elem_t* A;
-  long a_ps;  // plane stride (elements)
-  int lda;
+  int lda;  // elements
   const typename Op::elem_t* W;
-  long w_ps;
   int ldw;
   int M, N, K;
-  int krot;  // != 0: workgroup b starts its K loop at tile (b * krot) % KT (spreads concurrent reads of shared tiles over L2 channels)
+  // bits 0-7: K-loop rotation stride per workgroup (0 = off); bits 8-11: L2 touch-prefetch distance in K tiles;
+  // bit 12: ablation "no loads after tile 0"; bit 13: ablation "no compute"
+  int krot;
 };
 
-template <class Op, int BM, int BN, int BKB>
+constexpr int GEMM_BKB = 128;  // bytes per tile row per K tile, every mode
+
+template <int BM, int BN>
 struct GemmSmem {
   static constexpr int LDC = BN + 4;
-  static constexpr int STAGE = Op::NP * (BM + BN) * BKB;
+  static constexpr int STAGE = (BM + BN) * GEMM_BKB;
   static constexpr int CBYTES = BM * LDC * 4;
   static constexpr int BYTES = (2 * STAGE > CBYTES) ? 2 * STAGE : CBYTES;
 };
@@ -62,7 +68,6 @@ struct EpiBiasAct {
   const float* rowadd;  // [M][ld_rowadd] or null
   int ld_rowadd;
   typename OutOp::elem_t* out;
-  long out_ps;
   int ldo;
   int act;
   template <int BM, int BN, int NT>
@@ -98,7 +103,7 @@ struct EpiBiasAct {
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
         }
       }
-      OutOp::template store<8>(out, out_ps, (long)gr * ldo + gn, v);
+      OutOp::template store<8>(out, (long)gr * ldo + gn, v);
     }
   }
 };
@@ -109,9 +114,7 @@ template <class Op>
 struct EpiQKV {
   const float* bias;  // [3d]
   typename Op::elem_t* qk;
-  long qk_ps;
   typename Op::elem_t* vt;
-  long vt_ps;
   int d, H, hd, Sp, Skp;
   float qscale;
   template <int BM, int BN, int NT>
@@ -128,7 +131,7 @@ struct EpiQKV {
         g_load8(bias + gn, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
-        Op::template store<8>(qk, qk_ps, (long)gr * (2 * d) + gn, v);
+        Op::template store<8>(qk, (long)gr * (2 * d) + gn, v);
       }
     } else {
       for (int it = tid; it < (BM / 8) * BN; it += NT) {
@@ -142,7 +145,7 @@ struct EpiQKV {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Ct[(rg * 8 + j) * LDC + col] + bb;
-        Op::template store<8>(vt, vt_ps, ((long)(b * H + h) * hd + e) * Skp + s0, v);
+        Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
       }
     }
   }
@@ -158,7 +161,6 @@ struct EpiSeqRows {
   int pe_stride;
   float* xout;  // [rows][d] fp32 or null
   typename Op::elem_t* xop;  // operand planes or null
-  long xop_ps;
   int d, Tdiv, Sp, P;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
@@ -176,7 +178,7 @@ struct EpiSeqRows {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
       if (xout) g_store8(xout + orow * d + gn, v);
-      if (xop) Op::template store<8>(xop, xop_ps, orow * d + gn, v);
+      if (xop) Op::template store<8>(xop, orow * d + gn, v);
     }
   }
 };
@@ -190,7 +192,6 @@ struct EpiLN {
   const float* beta;
   float* xout;  // [M][d] (may alias resid: every row is read and written by the same wave)
   typename Op::elem_t* xop;
-  long xop_ps;
   float eps;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
@@ -238,7 +239,7 @@ struct EpiLN {
       } else {
         *(float2*)op = make_float2(v[0], v[1]);
       }
-      Op::template store<VPL>(xop, xop_ps, (long)gr * BN + c0, v);
+      Op::template store<VPL>(xop, (long)gr * BN + c0, v);
     }
   }
 };
@@ -255,7 +256,6 @@ struct EpiHead {
   const float* x_in;    // HEAD_RESIDUAL: (B, T, F)
   float* xs;            // HEAD_DDPM: state [B*T][XK]
   typename Op::elem_t* xs_op;
-  long xs_op_ps;
   const int* tcur;      // device: current timestep index of every clip (uniform inside the loop)
   const float* c1;
   const float* c2;
@@ -319,7 +319,7 @@ struct EpiHead {
           }
         }
         g_store8(xs + srow + gn, xn);
-        Op::template store<8>(xs_op, xs_op_ps, srow + gn, xn);
+        Op::template store<8>(xs_op, srow + gn, xn);
       }
     }
   }
@@ -361,148 +361,6 @@ struct EpiStoreF32 {
 // ------------------------------------------------------------------------------------------------
 // The kernel
 // ------------------------------------------------------------------------------------------------
-// waves per SIMD the kernel is built for: LDS admits 2 workgroups per CU for the 128x128 tiles, 1 for the 64xN ones;
-// telling the compiler keeps its occupancy heuristics from spilling / sinking the prefetch registers
-template <class Op, int BM, int BN, int BKB, int NWV = 4>
-struct GemmOcc {
-  static constexpr int WG_PER_CU = (GemmSmem<Op, BM, BN, BKB>::BYTES > 80 * 1024) ? 1 : 2;
-  static constexpr int WAVES_PER_SIMD = WG_PER_CU * NWV / 4;
-};
-
-template <class Op, int BM, int BN, int WGM, int WGN, int BKB, class Epi>
-__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB>::WAVES_PER_SIMD)) void gemm_kernel(const GemmArgs<Op> ga, const Epi epi) {
-  constexpr int NT = WGM * WGN * 64;
-  constexpr int NP = Op::NP;
-  constexpr int CPR = BKB / 16;  // 16-byte chunks per tile row
-  constexpr int WM = BM / WGM, WN = BN / WGN;
-  constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int A_CH = BM * CPR * NP, W_CH = BN * CPR * NP;
-  constexpr int A_PT = A_CH / NT, W_PT = W_CH / NT;
-  static_assert(A_CH % NT == 0 && W_CH % NT == 0, "staging must divide evenly");
-  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
-  typedef GemmSmem<Op, BM, BN, BKB> SM;
-  constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int M = ga.M;
-  const int KT = (ga.K * Op::EB) / BKB;
-
-  // per-thread staging slots: global byte offsets (without the k-tile term) and LDS byte offsets
-  long a_goff[A_PT], w_goff[W_PT];
-  int a_soff[A_PT], w_soff[W_PT];
-#pragma unroll
-  for (int i = 0; i < A_PT; ++i) {
-    const int q = tid + i * NT;
-    const int p = q / (BM * CPR), rem = q % (BM * CPR);
-    const int row = rem / CPR, ch = rem % CPR;
-    int gr = m0 + row;
-    gr = gr < M ? gr : M - 1;
-    a_goff[i] = ((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB + ch * 16;
-    a_soff[i] = p * A_BYTES + row * BKB + ((ch ^ swz_chunk<BKB>(row)) << 4);
-  }
-#pragma unroll
-  for (int i = 0; i < W_PT; ++i) {
-    const int q = tid + i * NT;
-    const int p = q / (BN * CPR), rem = q % (BN * CPR);
-    const int row = rem / CPR, ch = rem % CPR;
-    w_goff[i] = ((long)p * ga.w_ps + (long)(n0 + row) * ga.ldw) * Op::EB + ch * 16;
-    w_soff[i] = NP * A_BYTES + p * W_BYTES + row * BKB + ((ch ^ swz_chunk<BKB>(row)) << 4);
-  }
-  const char* Ab = (const char*)ga.A;
-  const char* Wb = (const char*)ga.W;
-
-  int4 ra[A_PT], rw[W_PT];
-#define TAMF_GLOAD(kt_)                                                                  \
-  {                                                                                      \
-    const long ko_ = (long)(kt_) * BKB;                                                  \
-    _Pragma("unroll") for (int i = 0; i < A_PT; ++i) ra[i] = *(const int4*)(Ab + a_goff[i] + ko_); \
-    _Pragma("unroll") for (int i = 0; i < W_PT; ++i) rw[i] = *(const int4*)(Wb + w_goff[i] + ko_); \
-  }
-#define TAMF_SWRITE(s_)                                                                  \
-  {                                                                                      \
-    char* sb_ = smem + (s_) * SM::STAGE;                                                 \
-    _Pragma("unroll") for (int i = 0; i < A_PT; ++i) *(int4*)(sb_ + a_soff[i]) = ra[i]; \
-    _Pragma("unroll") for (int i = 0; i < W_PT; ++i) *(int4*)(sb_ + w_soff[i]) = rw[i]; \
-  }
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int sw = swz_chunk<BKB>(lr);  // tile rows are multiples of 16 apart: the swizzle depends on lr only
-  const int a_frag = (wm0 + lr) * BKB;
-  const int w_frag = NP * A_BYTES + (wn0 + lr) * BKB;
-
-#define TAMF_COMPUTE(s_)                                                                                       \
-  {                                                                                                            \
-    const char* cb_ = smem + (s_) * SM::STAGE;                                                                 \
-    _Pragma("unroll") for (int kc = 0; kc < BKB / 64; ++kc) {                                                  \
-      const int coff = (((kc * 4 + g) ^ sw) << 4);                                                             \
-      int4 af[MI][NP];                                                                                         \
-      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int p = 0; p < NP; ++p)         \
-          af[mi][p] = *(const int4*)(cb_ + p * A_BYTES + a_frag + mi * 16 * BKB + coff);                       \
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                      \
-        int4 wf[NP];                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                         \
-            wf[p] = *(const int4*)(cb_ + p * W_BYTES + w_frag + ni * 16 * BKB + coff);                         \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf, af[mi]);                    \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-
-  const int rot = ga.krot ? (int)(((unsigned)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)ga.krot) % (unsigned)KT) : 0;
-  TAMF_GLOAD(rot)
-  TAMF_SWRITE(0)
-  __syncthreads();
-  // steady state: fetch tile kt+1 into registers while tile kt is multiplied out of LDS
-  for (int kt = 0; kt < KT - 1; ++kt) {
-    const int cur = kt & 1;
-    int ktn = kt + 1 + rot;
-    ktn = ktn >= KT ? ktn - KT : ktn;
-    TAMF_GLOAD(ktn)
-    // NOTE: hipcc sinks these prefetch loads towards the LDS stores below (shorter live ranges); pinning them with
-    // sched_barrier(0) makes it keep the staging arrays in scratch instead (2x slower).  v2 (LDS-DMA) avoids both.
-    TAMF_COMPUTE(cur)  // D rows = n (4g+reg), cols = m (lr)
-    TAMF_SWRITE(cur ^ 1)
-    __syncthreads();
-  }
-  TAMF_COMPUTE((KT - 1) & 1)
-  __syncthreads();
-#undef TAMF_GLOAD
-#undef TAMF_SWRITE
-#undef TAMF_COMPUTE
-
-  // park the accumulators in the LDS C tile: lane (g, lr) holds C[m = lr][n = 4g .. 4g+3] of each 16x16 tile
-  float* Ct = (float*)smem;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const f32x4 v = acc[mi][ni];
-      *(float4*)(Ct + (wm0 + mi * 16 + lr) * SM::LDC + wn0 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  __syncthreads();
-  epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
-}
-
-// ------------------------------------------------------------------------------------------------
-// v2: LDS-DMA staging.  Tiles go global -> LDS directly (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KiB
-// "piece" per wave-instruction, LDS destination = wave-uniform base + 16*lane), so there is no register staging
-// and no ds_write pass.  The LDS image is the same swizzled image as v1: because the DMA writes linearly, the
-// swizzle is applied to each lane's SOURCE address (lane -> (row, physical chunk) -> logical chunk = physical ^
-// swz(row)).  Tile k+1's pieces are issued interleaved with tile k's MFMA groups; one __syncthreads() per K tile
-// (it waits vmcnt(0) for the wave's own pieces, the barrier covers everybody else's).
-// The workgroup id is remapped so that all N-tiles of one M-tile run on the same XCD (A row panel fetched into one
-// L2 instead of eight).
-// ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void tamf_lds_void;
 typedef const __attribute__((address_space(1))) void tamf_gbl_void;
 
@@ -516,22 +374,29 @@ TAMF_DEV int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <class Op, int BM, int BN, int WGM, int WGN, int BKB, class Epi>
-__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel_v2(const GemmArgs<Op> ga, const Epi epi) {
+// waves per SIMD the kernel is built for (LDS admits 2 workgroups per CU for the 128 x 128 tiles, 1 for 64 x 512):
+// telling the compiler keeps its occupancy heuristics from squeezing the register budget
+template <int BM, int BN, int NWV>
+struct GemmOcc {
+  static constexpr int WG_PER_CU = (GemmSmem<BM, BN>::BYTES > 80 * 1024) ? 1 : 2;
+  static constexpr int WAVES_PER_SIMD = (WG_PER_CU * NWV / 4) > 0 ? (WG_PER_CU * NWV / 4) : 1;
+};
+
+template <class Op, int BM, int BN, int WGM, int WGN, class Epi>
+__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel(
+    const GemmArgs<Op> ga, const Epi epi) {
+  constexpr int BKB = GEMM_BKB;
   constexpr int NT = WGM * WGN * 64;
   constexpr int NWV = WGM * WGN;
-  constexpr int NP = Op::NP;
-  constexpr int CPR = BKB / 16;    // 16-byte chunks per tile row
-  constexpr int RPI = 1024 / BKB;  // tile rows per 1-KiB piece
+  constexpr int CPR = BKB / 16;    // 16-byte chunks per tile row (8)
+  constexpr int RPI = 1024 / BKB;  // tile rows per 1-KiB piece (8)
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int A_PIECES = NP * BM / RPI, W_PIECES = NP * BN / RPI;
-  constexpr int A_PW = A_PIECES / NWV, W_PW = W_PIECES / NWV;
-  static_assert(A_PIECES % NWV == 0 && W_PIECES % NWV == 0, "pieces must divide over the waves");
-  typedef GemmSmem<Op, BM, BN, BKB> SM;
-  constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB;
-  constexpr int KCN = BKB / 64;
-  constexpr int TOT_PW = A_PW + W_PW;
+  constexpr int A_PIECES = BM / RPI, W_PIECES = BN / RPI;
+  constexpr int A_PW = (A_PIECES + NWV - 1) / NWV, W_PW = (W_PIECES + NWV - 1) / NWV;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
+  typedef GemmSmem<BM, BN> SM;
+  constexpr int A_BYTES = BM * BKB;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -545,28 +410,62 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB, WGM * WGN>
   const int n0 = (lb % ntn) * BN, m0 = (lb / ntn) * BM;
   const int M = ga.M;
   const int KT = (ga.K * Op::EB) / BKB;
+  const char* Ab = (const char*)ga.A;
+  const char* Wb = (const char*)ga.W;
 
-  // per-piece source byte offsets of this lane (k-tile term added at issue time) and wave-uniform LDS offsets
+  // per-piece source byte offsets of this lane (k-tile term added at issue time); piece q of the A (W) tile is
+  // handled by wave q % NWV and covers tile rows [8q, 8q+8)
   unsigned a_off[A_PW], w_off[W_PW];
   const int prow = lane / CPR, pch = lane % CPR;
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
-    const int q = wave + i * NWV;
-    const int p = q / (BM / RPI), jr = q % (BM / RPI);
-    const int row = jr * RPI + prow;
+    const int row = (wave + i * NWV) * RPI + prow;
     int gr = m0 + row;
     gr = gr < M ? gr : M - 1;
-    a_off[i] = (unsigned)(((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
+    a_off[i] = (unsigned)((long)gr * ga.lda * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
   }
 #pragma unroll
   for (int i = 0; i < W_PW; ++i) {
-    const int q = wave + i * NWV;
-    const int p = q / (BN / RPI), jr = q % (BN / RPI);
-    const int row = jr * RPI + prow;
-    w_off[i] = (unsigned)(((long)p * ga.w_ps + (long)(n0 + row) * ga.ldw) * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
+    const int row = (wave + i * NWV) * RPI + prow;
+    w_off[i] = (unsigned)((long)(n0 + (row < BN ? row : BN - 1)) * ga.ldw * Op::EB + ((pch ^ swz_chunk<BKB>(row)) << 4));
   }
-  const char* Ab = (const char*)ga.A;
-  const char* Wb = (const char*)ga.W;
+
+#define TAMF_ISSUE_ALL(kt_, s_)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int ii = 0; ii < A_PW; ++ii) {                                            \
+      const int q_ = wave + ii * NWV;                                                                \
+      if (A_PIECES % NWV == 0 || q_ < A_PIECES)                                                      \
+        glds16(Ab + a_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + q_ * 1024);             \
+    }                                                                                                \
+    _Pragma("unroll") for (int ii = 0; ii < W_PW; ++ii) {                                            \
+      const int q_ = wave + ii * NWV;                                                                \
+      if (W_PIECES % NWV == 0 || q_ < W_PIECES)                                                      \
+        glds16(Wb + w_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + A_BYTES + q_ * 1024);   \
+    }                                                                                                \
+  }
+
+  // L2 prefetch by touch: waves 0..3 each issue ONE sparse dword load (L1-bypassing, sc1) per K tile that pulls the
+  // lines of tile kt+pf into the XCD's L2, so the LDS-DMA of that tile later sees L2-hit instead of MALL/HBM latency;
+  // no LDS is needed for this extra prefetch depth.  Rows touched by this workgroup: its own A rows (waves 0,1) and a
+  // 1/8 slice of the W rows (waves 2,3) - the other workgroups sharing the XCD cover the other slices.
+  const int pf = (ga.krot >> 8) & 0xF;
+  const char* tbase = nullptr;
+  {
+    const int peer = (blockIdx.x >> 3) & 7;
+    if (wave < 2) {
+      const int r = wave * 64 + lane;
+      if (r < BM) {
+        int gr = m0 + r;
+        gr = gr < M ? gr : M - 1;
+        tbase = Ab + (long)gr * ga.lda * Op::EB;
+      }
+    } else if (wave < 4) {
+      constexpr int WSL = BN / 8;
+      const int j = (wave - 2) * 64 + lane;
+      if (j < WSL) tbase = Wb + (long)(n0 + peer * WSL + j) * ga.ldw * Op::EB;
+    }
+  }
+  unsigned tsink = 0;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -574,55 +473,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB, WGM * WGN>
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // fragment addressing: lane (lr, g) reads chunks g and 4+g of tile row lr (+16 per MFMA tile); the row swizzle
+  // depends on lr only because tile rows are multiples of 16 apart
   const int sw = swz_chunk<BKB>(lr);
+  const int c0 = ((g ^ sw) << 4), c1 = (((4 + g) ^ sw) << 4);
   const int a_frag = (wm0 + lr) * BKB;
-  const int w_frag = NP * A_BYTES + (wn0 + lr) * BKB;
+  const int w_frag = A_BYTES + (wn0 + lr) * BKB;
 
-  // prologue: tile 0
-#define TAMF_ISSUE_ALL(kt_, s_)                                                       \
-  {                                                                                   \
-    _Pragma("unroll") for (int ii = 0; ii < TOT_PW; ++ii) {                           \
-      if (ii < A_PW) {                                                                \
-        const int pq_ = wave + ii * NWV;                                              \
-        glds16(Ab + a_off[ii < A_PW ? ii : 0] + (long)(kt_) * BKB,                    \
-               smem + (s_) * SM::STAGE + (pq_ / (BM / RPI)) * A_BYTES + (pq_ % (BM / RPI)) * 1024); \
-      } else {                                                                        \
-        const int pq_ = wave + (ii - A_PW) * NWV;                                     \
-        glds16(Wb + w_off[ii >= A_PW ? ii - A_PW : 0] + (long)(kt_) * BKB,            \
-               smem + (s_) * SM::STAGE + NP * A_BYTES + (pq_ / (BN / RPI)) * W_BYTES + (pq_ % (BN / RPI)) * 1024); \
-      }                                                                               \
-    }                                                                                 \
-  }
-  // L2 prefetch by touch: waves 0..3 each issue ONE sparse dword load (L1-bypassing, sc1) per K tile that pulls the
-  // lines of tile kt+PF into the XCD's L2, so the LDS-DMA of that tile later sees L2-hit instead of MALL/HBM latency.
-  // No LDS is needed for this extra prefetch depth.  Rows touched by this workgroup: all of its own A rows (waves
-  // 0,1) and a 1/8 slice of the W rows (waves 2,3) - the ~26 workgroups sharing the XCD cover the other slices.
-  const int pf = (ga.krot >> 8) & 0xF;
-  const char* tbase = nullptr;   // per-lane touch address for tile 0 (null: this lane does not touch)
-  {
-    const int peer = (blockIdx.x >> 3) & 7;
-    if (wave < 2) {
-      const int r = wave * 64 + lane;  // A row slot: plane-major
-      if (r < NP * BM) {
-        const int p = r / BM;
-        int gr = m0 + r % BM;
-        gr = gr < M ? gr : M - 1;
-        tbase = Ab + ((long)p * ga.a_ps + (long)gr * ga.lda) * Op::EB;
-      }
-    } else if (wave < 4) {
-      constexpr int WSL = NP * BN / 8;  // W row slots of this workgroup's slice
-      const int j = (wave - 2) * 64 + lane;
-      if (j < WSL) {
-        const int r = peer * WSL + j;
-        const int p = r / BN;
-        tbase = Wb + ((long)p * ga.w_ps + (long)(n0 + r % BN) * ga.ldw) * Op::EB;
-      }
-    }
-  }
-  unsigned tsink = 0;
-
-  // krot: bits 0-7 = rotation stride; bits 8-11 = L2 touch-prefetch distance in K tiles (0 = off);
-  // bit 12 = ablation "no loads after tile 0"; bit 13 = ablation "no compute"
   const int krs = ga.krot & 0xFF;
   const bool abl_noload = (ga.krot & 0x1000) != 0, abl_nocomp = (ga.krot & 0x2000) != 0;
   const int rot = krs ? (int)(((unsigned)lb * (unsigned)krs) % (unsigned)KT) : 0;
@@ -635,40 +492,39 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<Op, BM, BN, BKB, WGM * WGN>
     int ktn = kt + 1 + rot;
     ktn = ktn >= KT ? ktn - KT : ktn;
     const char* cb = smem + cur * SM::STAGE;
-    // next tile's pieces first: their latency is covered by this tile's MFMAs (waited for at the barrier below)
     unsigned tv = 0;
     if (pf && tbase && kt + pf < KT) {
       int ktp = kt + pf + rot;
       ktp = ktp >= KT ? ktp - KT : ktp;
       tv = __hip_atomic_load((const unsigned*)(tbase + (long)ktp * BKB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // next tile's pieces first: their latency is covered by this tile's MFMAs (waited for at the barrier below)
     if (more) TAMF_ISSUE_ALL(ktn, cur ^ 1)
     if (!abl_nocomp) {
+      // all fragments of the tile are requested up front: LDS latency is paid once and the MFMAs stream behind
+      // counted lgkmcnt waits
+      int4 af[MI][2], wf[NI][2];
 #pragma unroll
-      for (int kc = 0; kc < KCN; ++kc) {
-        const int coff = (((kc * 4 + g) ^ sw) << 4);
-        // all fragments of the K chunk are requested up front, so LDS latency is paid once per chunk and the
-        // MFMAs stream behind counted lgkmcnt waits
-        int4 af[MI][NP], wf[NI][NP];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) af[mi][p] = *(const int4*)(cb + p * A_BYTES + a_frag + mi * 16 * BKB + coff);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) wf[ni][p] = *(const int4*)(cb + p * W_BYTES + w_frag + ni * 16 * BKB + coff);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);
+      for (int mi = 0; mi < MI; ++mi) {
+        af[mi][0] = *(const int4*)(cb + a_frag + mi * 16 * BKB + c0);
+        af[mi][1] = *(const int4*)(cb + a_frag + mi * 16 * BKB + c1);
       }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        wf[ni][0] = *(const int4*)(cb + w_frag + ni * 16 * BKB + c0);
+        wf[ni][1] = *(const int4*)(cb + w_frag + ni * 16 * BKB + c1);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g+reg), cols = m (lr)
     }
     __syncthreads();
     tsink ^= tv;  // consumed after the barrier's vmcnt(0): keeps the touch load alive without an extra wait
   }
 #undef TAMF_ISSUE_ALL
 
+  // park the accumulators in the LDS C tile: lane (g, lr) holds C[m = lr][n = 4g .. 4g+3] of each 16x16 tile
   float* Ct = (float*)smem;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)

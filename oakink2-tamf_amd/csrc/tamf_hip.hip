@@ -52,7 +52,7 @@ struct tamf_ctx {
   int d = 0, ff = 0, L = 0, H = 0, hd = 0, P = 0, F = 0, has_t = 0;
   int XK = 0;   // padded K of the fused input GEMM
   int XN = 128; // padded N of the output head
-  int NP = 1, EB = 4;
+  int EB = 4;  // bytes per logical operand element (f32 4, bf16 2, bf16x3 4 = hi + lo)
   std::string err;
   std::vector<void*> allocs;
   std::map<std::string, std::vector<float>> raw;
@@ -144,100 +144,98 @@ static inline float h_bf2f(uint16_t h) {
   return f;
 }
 
-// upload host fp32 [N][K] as operand planes [NP][N][ldk] in precision `prec` (cols >= K zero)
+// upload host fp32 [N][K] as an operand matrix [N][ldk] in precision `prec` (cols >= K zero; ldk % 32 == 0).
+// bf16x3 rows are 128-byte groups of 32 elements: [hi: 32 bf16 | lo: 32 bf16] (tamf_device.h "Operand traits").
 static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out) {
   const size_t n = (size_t)N * ldk;
-  out->ps = (long)n;
+  out->ps = 0;
+  if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
     for (int r = 0; r < N; ++r) memcpy(&h[(size_t)r * ldk], &w[(size_t)r * K], (size_t)K * 4);
     return dev_upload(ctx, (float**)&out->p, h.data(), n);
   }
-  const int np = prec == TAMF_PREC_BF16X3 ? 2 : 1;
-  std::vector<uint16_t> h(n * np, 0);
+  if (prec == TAMF_PREC_BF16) {
+    std::vector<uint16_t> h(n, 0);
+    for (int r = 0; r < N; ++r)
+      for (int k = 0; k < K; ++k) h[(size_t)r * ldk + k] = h_f2bf(w[(size_t)r * K + k]);
+    return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n);
+  }
+  std::vector<uint16_t> h(n * 2, 0);
   for (int r = 0; r < N; ++r)
     for (int k = 0; k < K; ++k) {
       const float v = w[(size_t)r * K + k];
       const uint16_t hi = h_f2bf(v);
-      h[(size_t)r * ldk + k] = hi;
-      if (np == 2) h[n + (size_t)r * ldk + k] = h_f2bf(v - h_bf2f(hi));
+      const size_t idx = (size_t)r * ldk + k;
+      const size_t o = (idx >> 5) * 64 + (idx & 31);  // in uint16 units: 64 per 128-byte group
+      h[o] = hi;
+      h[o + 32] = h_f2bf(v - h_bf2f(hi));
     }
-  return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * np);
+  return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * 2);
 }
 
 // ------------------------------------------------------------------------------------------------
 // kernel launchers
 // ------------------------------------------------------------------------------------------------
-// K-loop rotation stride per workgroup (0 = off).  TAMF_GEMM_KROT overrides.
+// GemmArgs::krot bits (tamf_gemm.h): rotation stride, L2 touch-prefetch distance, ablation flags.
+// -1 = per-kernel default: the 64-row LayerNorm tiles prefetch 4 K tiles ahead into L2 (their weight panel is shared by
+// every workgroup and has been evicted from the 4 MB L2 by the other GEMMs of the layer: 186 -> 153 us in situ), the
+// 128 x 128 tiles do not (it costs them 5-8 %).  TAMF_GEMM_KROT / tamf_set_gemm_tuning override both.
 static int g_krot = []() {
   const char* e = getenv("TAMF_GEMM_KROT");
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : -1;
 }();
+static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
-// kernel variant: 1 = register-staged (v1), 2 = LDS-DMA staged + XCD-aware tile order (v2).  TAMF_GEMM_VARIANT overrides.
-static int g_gemm_variant = []() {
-  const char* e = getenv("TAMF_GEMM_VARIANT");
-  return e ? atoi(e) : 2;
-}();
-
-template <class Op, int BM, int BN, int BKB, class Epi>
+template <class Op, int BM, int BN, class Epi>
 struct GemmLaunch {
-  static constexpr int SMEM = GemmSmem<Op, BM, BN, BKB>::BYTES;
-  // v2 wave grid: the 64-row LayerNorm tiles run 8 waves (2 x 4) so that two waves share each SIMD and cover each
+  static constexpr int SMEM = GemmSmem<BM, BN>::BYTES;
+  // wave grid: the 64-row LayerNorm tiles run 8 waves (2 x 4) so that two waves share each SIMD and cover each
   // other's LDS / barrier latency; the 128 x 128 tiles run 4 waves (2 x 2) with two workgroups per CU
-  static constexpr int V2_WGN = (BM == 64) ? 4 : 2;
+  static constexpr int WGN = (BM == 64) ? 4 : 2;
   static hipError_t prepare() {
     static bool done = false;
     if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, WGN, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm_kernel_v2<Op, BM, BN, 2, V2_WGN, BKB, Epi>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e == hipSuccess) done = true;
     return e;
   }
   static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    if ((ga.K * Op::EB) % BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
+    if ((ga.K * Op::EB) % GEMM_BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
     const int ntn = ga.N / BN, ntm = (ga.M + BM - 1) / BM;
-    if (g_gemm_variant == 1) {
-      hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, 2, BKB, Epi>), dim3(ntn, ntm), dim3(256), SMEM, st, ga, epi);
-    } else {
-      hipLaunchKernelGGL((gemm_kernel_v2<Op, BM, BN, 2, V2_WGN, BKB, Epi>), dim3(ntn * ntm), dim3(2 * V2_WGN * 64), SMEM, st, ga, epi);
-    }
+    GemmArgs<Op> gb = ga;
+    gb.krot = krot_for(BM == 64);
+    hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi>), dim3(ntn * ntm), dim3(2 * WGN * 64), SMEM, st, gb, epi);
     return hipGetLastError();
   }
 };
-template <class Op>
-struct TileCfg {
-  static constexpr int BKB = Op::NP == 2 ? 64 : 128;
-};
 template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
-  return GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, Epi>::launch(ga, epi, st);
+  return GemmLaunch<Op, 128, 128, Epi>::launch(ga, epi, st);
 }
 template <class Op>
 static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st) {
   switch (ga.N) {
-    case 128: return GemmLaunch<Op, 64, 128, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
-    case 256: return GemmLaunch<Op, 64, 256, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
-    case 512: return GemmLaunch<Op, 64, 512, TileCfg<Op>::BKB, EpiLN<Op>>::launch(ga, epi, st);
+    case 128: return GemmLaunch<Op, 64, 128, EpiLN<Op>>::launch(ga, epi, st);
+    case 256: return GemmLaunch<Op, 64, 256, EpiLN<Op>>::launch(ga, epi, st);
+    case 512: return GemmLaunch<Op, 64, 512, EpiLN<Op>>::launch(ga, epi, st);
     default: return hipErrorInvalidValue;
   }
 }
 template <class Op>
 static hipError_t prepare_all() {
   hipError_t e;
-  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiHead<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, TileCfg<Op>::BKB, EpiStoreF32>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 128, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 256, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 512, TileCfg<Op>::BKB, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -267,7 +265,7 @@ extern "C" const char* tamf_last_error(const tamf_ctx* ctx) { return ctx ? ctx->
 
 static int alloc_operand(tamf_ctx* ctx, OperandBuf* ob, long elems, bool zero = false) {
   ob->ps = elems;
-  return dev_alloc(ctx, &ob->p, (size_t)elems * ctx->NP * ctx->EB, zero);
+  return dev_alloc(ctx, &ob->p, (size_t)elems * ctx->EB, zero);
 }
 
 extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames, int32_t precision,
@@ -307,8 +305,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   ctx->has_t = arch->kind == TAMF_KIND_G ? 1 : 0;
   ctx->P = arch->kind == TAMF_KIND_G ? 5 : 3;
   ctx->XK = arch->kind == TAMF_KIND_G ? 128 : round_up(arch->input_dim + arch->h2o_dim, 64);
-  ctx->NP = precision == TAMF_PREC_BF16X3 ? 2 : 1;
-  ctx->EB = precision == TAMF_PREC_F32 ? 4 : 2;
+  ctx->EB = precision == TAMF_PREC_BF16 ? 2 : 4;
   ctx->layers.resize(ctx->L);
 
   auto bail = [&](int rc) {
@@ -525,11 +522,11 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     float* tmp = nullptr;
     TRY(dev_alloc(ctx, (void**)&ctx->temb, (size_t)ctx->n_t * d * 4));
     TRY(dev_alloc(ctx, (void**)&tmp, (size_t)ctx->n_t * d * 4));
-    GemmArgs<OpF32> g1{ctx->pe, 0, d, (const float*)ctx->Wt1_f32.p, 0, d, ctx->n_t, d, d, g_krot};
-    EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, 0, d, ACT_SILU};
+    GemmArgs<OpF32> g1{ctx->pe, d, (const float*)ctx->Wt1_f32.p, d, ctx->n_t, d, d, 0};
+    EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, d, ACT_SILU};
     HIPCHK(ctx, gemm128<OpF32>(g1, e1, st));
-    GemmArgs<OpF32> g2{tmp, 0, d, (const float*)ctx->Wt2_f32.p, 0, d, ctx->n_t, d, d, g_krot};
-    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, 0, d, 0x7FFFFFFF, 0, 0};
+    GemmArgs<OpF32> g2{tmp, d, (const float*)ctx->Wt2_f32.p, d, ctx->n_t, d, d, 0};
+    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, d, 0x7FFFFFFF, 0, 0};
     HIPCHK(ctx, gemm128<OpF32>(g2, e2, st));
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
@@ -612,8 +609,8 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
   hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd);
   hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * T * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wq, ctx->bq,
                      ctx->objfeat, (long)B * T, d, qd);
-  GemmArgs<OpF32> ga{ctx->objfeat, 0, d, (const float*)ctx->Wm1b_f32.p, 0, d, B * T, d, d, g_krot};
-  EpiBiasAct<OpF32> ep{ctx->cbias, nullptr, 0, ctx->cobj, 0, d, ACT_NONE};
+  GemmArgs<OpF32> ga{ctx->objfeat, d, (const float*)ctx->Wm1b_f32.p, d, B * T, d, d, 0};
+  EpiBiasAct<OpF32> ep{ctx->cbias, nullptr, 0, ctx->cobj, d, ACT_NONE};
   HIPCHK(ctx, gemm128<OpF32>(ga, ep, st));
   HIPCHK(ctx, hipGetLastError());
   ctx->cond_set = true;
@@ -643,19 +640,19 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   {
     const int rows = P + (Sp - S);
     hipLaunchKernelGGL((prefix_fill_kernel<Op>), grid1d((long)B * rows * (d / 8)), dim3(256), 0, st, ctx->X, (E*)ctx->X_op.p,
-                       ctx->X_op.ps, ctx->temb, ctx->tcur, ctx->pstatic, B, d, P, ctx->has_t, S, Sp);
+                       ctx->temb, ctx->tcur, ctx->pstatic, B, d, P, ctx->has_t, S, Sp);
     mark("prefix_fill", ctx->has_t ? B * 4.0 * dd * dd : 0.0);
   }
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
-    GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->xs_op.ps, ctx->XK, (const E*)ctx->Wfused.p, ctx->Wfused.ps, ctx->XK, B * T, d, ctx->XK, g_krot};
-    EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, ctx->h1_op.ps, d, ACT_SILU};
+    GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->XK, (const E*)ctx->Wfused.p, ctx->XK, B * T, d, ctx->XK, 0};
+    EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, d, ACT_SILU};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge0", BT * (2.0 * F * dd + 2.0 * dd * (ctx->arch.kind == TAMF_KIND_R ? 3 : 2) * dd +
                                     (ctx->arch.kind == TAMF_KIND_R ? 2.0 * ctx->arch.h2o_dim * dd : 0.0)));
   }
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
-    GemmArgs<Op> ga{(const E*)ctx->h1_op.p, ctx->h1_op.ps, d, (const E*)ctx->Wm2.p, ctx->Wm2.ps, d, B * T, d, d, g_krot};
-    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, d, T, Sp, P};
+    GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd);
   }
@@ -663,37 +660,37 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   for (int l = 0; l < ctx->L; ++l) {
     const LayerW& w = ctx->layers[l];
     {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.Win.p, w.Win.ps, d, M, 3 * d, d, g_krot};
-      EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, ctx->QK_op.ps, (E*)ctx->Vt_op.p, ctx->Vt_op.ps, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
+      EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
-      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, ctx->QK_op.ps, (const E*)ctx->Vt_op.p, ctx->Vt_op.ps, (E*)ctx->A_op.p, ctx->A_op.ps, S, Sp, ctx->Skp, d, ctx->H};
+      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H};
       HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
       mark("attention", 4.0 * B * (double)S * S * dd);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->A_op.p, ctx->A_op.ps, d, (const E*)w.Wout.p, w.Wout.ps, d, M, d, d, g_krot};
-      EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
+      GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
+      EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
       mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)w.W1.p, w.W1.ps, d, M, ff, d, g_krot};
-      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ctx->H_op.ps, ff, ACT_GELU};
+      GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
+      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
       HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
-      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ctx->H_op.ps, ff, (const E*)w.W2.p, w.W2.ps, ff, M, d, ff, g_krot};
-      EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, ctx->X_op.ps, 1e-5f};
+      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
+      EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f};
       HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
       mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
     }
   }
   {
-    GemmArgs<Op> ga{(const E*)ctx->X_op.p, ctx->X_op.ps, d, (const E*)ctx->Wf.p, ctx->Wf.ps, d, M, ctx->XN, d, g_krot};
+    GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)ctx->Wf.p, d, M, ctx->XN, d, 0};
     HIPCHK(ctx, gemm128<Op>(ga, head_in, st));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
@@ -713,7 +710,6 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.XK = ctx->XK;
   h.xs = ctx->xs;
   h.xs_op = (typename Op::elem_t*)ctx->xs_op.p;
-  h.xs_op_ps = ctx->xs_op.ps;
   h.tcur = ctx->tcur;
   h.c1 = ctx->c1;
   h.c2 = ctx->c2;
@@ -728,7 +724,7 @@ static int denoise_impl(tamf_ctx* ctx, const float* x, const int64_t* t_dev, flo
   typedef typename Op::elem_t E;
   const int B = ctx->B, T = ctx->T;
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x, ctx->xs, (E*)ctx->xs_op.p,
-                     ctx->xs_op.ps, B, ctx->F, T, ctx->XK, 0, 0ull, 0ll);
+                     B, ctx->F, T, ctx->XK, 0, 0ull, 0ll);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)t_dev, 0, B);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_X0);
   h.x0_out = out;
@@ -755,7 +751,7 @@ static int refine_impl(tamf_ctx* ctx, const float* x_in, const float* h2o, float
   typedef typename Op::elem_t E;
   const int B = ctx->B, T = ctx->T;
   hipLaunchKernelGGL((refine_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x_in, h2o, (E*)ctx->xs_op.p,
-                     ctx->xs_op.ps, B * T, ctx->F, ctx->arch.h2o_dim, ctx->XK);
+                     B * T, ctx->F, ctx->arch.h2o_dim, ctx->XK);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_RESIDUAL);
   h.x0_out = out;
   h.x_in = x_in;
@@ -798,7 +794,7 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
   const int B = ctx->B, T = ctx->T, N = ctx->n_steps;
   // draw 0 = x_T
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, noise, ctx->xs,
-                     (E*)ctx->xs_op.p, ctx->xs_op.ps, B, ctx->F, T, ctx->XK, noise ? 0 : 1, (unsigned long long)seed,
+                     (E*)ctx->xs_op.p, B, ctx->F, T, ctx->XK, noise ? 0 : 1, (unsigned long long)seed,
                      (long long)clip_base);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
@@ -924,16 +920,16 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
   const int Kp = round_up(K, 64);
   TmpBufs tb;
-  E* ao = (E*)tb.get((size_t)M * Kp * Op::NP * Op::EB);
-  E* wo = (E*)tb.get((size_t)N * Kp * Op::NP * Op::EB);
-  E* yo = (E*)tb.get((size_t)M * N * Op::NP * Op::EB);
+  E* ao = (E*)tb.get((size_t)M * Kp * Op::EB);
+  E* wo = (E*)tb.get((size_t)N * Kp * Op::EB);
+  E* yo = (E*)tb.get((size_t)M * N * Op::EB);
   if (!ao || !wo || !yo) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
-  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)M * (Kp / 8)), dim3(256), 0, st, a, ao, (long)M * Kp, (long)M, K, Kp);
-  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)N * (Kp / 8)), dim3(256), 0, st, w, wo, (long)N * Kp, (long)N, K, Kp);
-  GemmArgs<Op> ga{ao, (long)M * Kp, Kp, wo, (long)N * Kp, Kp, M, N, Kp, g_krot};
+  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)M * (Kp / 8)), dim3(256), 0, st, a, ao, (long)M, K, Kp);
+  hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)N * (Kp / 8)), dim3(256), 0, st, w, wo, (long)N, K, Kp);
+  GemmArgs<Op> ga{ao, Kp, wo, Kp, M, N, Kp, 0};
   hipError_t e;
   if (ln) {
-    EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, (long)M * N, 1e-5f};
+    EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, 1e-5f};
     e = gemm_ln<Op>(ga, ep, st);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
@@ -978,18 +974,18 @@ static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* 
   const long M = (long)B * Sp;
   TmpBufs tb;
   const size_t qk_n = (size_t)M * 2 * d, vt_n = (size_t)B * d * Skp, o_n = (size_t)M * d;
-  E* qk = (E*)tb.get(qk_n * Op::NP * Op::EB);
-  E* vt = (E*)tb.get(vt_n * Op::NP * Op::EB);
-  E* oo = (E*)tb.get(o_n * Op::NP * Op::EB);
+  E* qk = (E*)tb.get(qk_n * Op::EB);
+  E* vt = (E*)tb.get(vt_n * Op::EB);
+  E* oo = (E*)tb.get(o_n * Op::EB);
   float* of = (float*)tb.get(o_n * 4);
   if (!qk || !vt || !oo || !of) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
-  (void)hipMemsetAsync(vt, 0, vt_n * Op::NP * Op::EB, st);
+  (void)hipMemsetAsync(vt, 0, vt_n * Op::EB, st);
   const float qscale = 1.4426950408889634f / sqrtf((float)hd);
-  hipLaunchKernelGGL((qkv_pack_kernel<Op>), grid1d(M * 3 * d), dim3(256), 0, st, qkv, qk, (long)qk_n, vt, (long)vt_n, B, S, Sp, Skp, H, hd, qscale);
-  AttnArgs<Op> aa{qk, (long)qk_n, vt, (long)vt_n, oo, (long)o_n, S, Sp, Skp, d, H};
+  hipLaunchKernelGGL((qkv_pack_kernel<Op>), grid1d(M * 3 * d), dim3(256), 0, st, qkv, qk, vt, B, S, Sp, Skp, H, hd, qscale);
+  AttnArgs<Op> aa{qk, vt, oo, S, Sp, Skp, d, H};
   hipError_t e = launch_attn<Op>(aa, B, hd, st);
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("attn launch: ") + hipGetErrorString(e));
-  hipLaunchKernelGGL((unpack_operand_kernel<Op>), grid1d(M * d), dim3(256), 0, st, oo, (long)o_n, of, M, d, d);
+  hipLaunchKernelGGL((unpack_operand_kernel<Op>), grid1d(M * d), dim3(256), 0, st, oo, of, M, d, d);
   // compact [B][Sp][d] -> [B][S][d]
   for (int b = 0; b < B; ++b)
     (void)hipMemcpyAsync(out + (size_t)b * S * d, of + (size_t)b * Sp * d, (size_t)S * d * 4, hipMemcpyDeviceToDevice, st);
@@ -1013,7 +1009,7 @@ extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int3
 
 // random operand fill for the kernel benchmarks (values in [-1, 1))
 template <class Op>
-__global__ void fill_operand_kernel(typename Op::elem_t* out, long ps, long n, unsigned salt) {
+__global__ void fill_operand_kernel(typename Op::elem_t* out, long n, unsigned salt) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i >= n) return;
   float v[8];
@@ -1023,7 +1019,7 @@ __global__ void fill_operand_kernel(typename Op::elem_t* out, long ps, long n, u
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     v[j] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
   }
-  Op::template store<8>(out, ps, i, v);
+  Op::template store<8>(out, i, v);
 }
 
 template <class Op>
@@ -1032,32 +1028,32 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
   if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
   TmpBufs tb;
   const long an = (long)M * K, wn = (long)N * K, on = (long)M * N;
-  E* a = (E*)tb.get((size_t)an * Op::NP * Op::EB);
-  E* w = (E*)tb.get((size_t)wn * Op::NP * Op::EB);
-  E* o = (E*)tb.get((size_t)on * Op::NP * Op::EB);
-  E* o2 = (E*)tb.get((size_t)on * Op::NP * Op::EB);
+  E* a = (E*)tb.get((size_t)an * Op::EB);
+  E* w = (E*)tb.get((size_t)wn * Op::EB);
+  E* o = (E*)tb.get((size_t)on * Op::EB);
+  E* o2 = (E*)tb.get((size_t)on * Op::EB);
   float* x = (float*)tb.get((size_t)on * 4);
   float* vec = (float*)tb.get((size_t)N * 4 * 4);
   if (!a || !w || !o || !o2 || !x || !vec) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
-  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(an / 8), dim3(256), 0, st, a, an, an, 1u);
-  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(wn / 8), dim3(256), 0, st, w, wn, wn, 2u);
-  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(on / 8), dim3(256), 0, st, x, on, on, 3u);
-  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, (long)N * 4, 4u);
-  GemmArgs<Op> ga{a, an, K, w, wn, K, M, N, K, g_krot};
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(an / 8), dim3(256), 0, st, a, an, 1u);
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(wn / 8), dim3(256), 0, st, w, wn, 2u);
+  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(on / 8), dim3(256), 0, st, x, on, 3u);
+  hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, 4u);
+  GemmArgs<Op> ga{a, K, w, K, M, N, K, 0};
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
   hipError_t e = hipSuccess;
   for (int it = -2; it < iters && e == hipSuccess; ++it) {
     if (it == 0) (void)hipEventRecord(e0, st);
     if (epi_kind == 2) {
-      EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, on, 1e-5f};
+      EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, 1e-5f};
       e = gemm_ln<Op>(ga, ep, st);
     } else if (epi_kind == 1) {
       const int d = N / 3;
-      EpiQKV<Op> ep{vec, o, on, o2, on, d, d / 128, 128, 208, 224, 0.1f};
+      EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
       e = gemm128<Op>(ga, ep, st);
     } else {
-      EpiBiasAct<Op> ep{vec, nullptr, 0, o, on, N, ACT_GELU};
+      EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
       e = gemm128<Op>(ga, ep, st);
     }
   }
@@ -1073,15 +1069,12 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
   return 0;
 }
 
-extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t variant, int32_t M, int32_t N, int32_t K,
+extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                                int32_t iters, float* ms_out, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
   if (epi_kind == 1 && (N % 384 || M % 208)) return fail(nullptr, TAMF_ERR_INVALID, "qkv bench needs N = 3d, M multiple of 208");
-  const int saved = g_gemm_variant, saved_rot = g_krot;
-  if (variant > 0) {  // variant = main-loop variant + 10 * krot (krot bits 12/13 = ablation flags, tamf_gemm.h)
-    g_gemm_variant = variant % 10;
-    g_krot = variant / 10;
-  }
+  const int saved_rot = g_krot;
+  g_krot = krot;  // -1 = per-kernel default; >= 0 = GemmArgs::krot bits (tamf_gemm.h)
   hipStream_t st = (hipStream_t)stream;
   int rc;
   switch (precision) {
@@ -1090,15 +1083,12 @@ extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t vari
     case TAMF_PREC_BF16X3: rc = bench_gemm_impl<OpBF16X3>(epi_kind, M, N, K, iters, ms_out, st); break;
     default: rc = fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   }
-  g_gemm_variant = saved;
   g_krot = saved_rot;
   return rc;
 }
 
-extern "C" int tamf_set_gemm_variant(int32_t variant) {
-  if (variant % 10 != 1 && variant % 10 != 2) return fail(nullptr, TAMF_ERR_INVALID, "variant must be 1 or 2 (+10*krot)");
-  g_gemm_variant = variant % 10;
-  g_krot = variant / 10;
+extern "C" int tamf_set_gemm_tuning(int32_t krot) {
+  g_krot = krot;
   return 0;
 }
 

@@ -6,8 +6,7 @@
 // (B, F, 1, T) reference layout -> frame-major sampler state [B*T][XK] (+ operand planes); cols >= F are zero.
 // draw0 != 0: ignore x and fill with Philox draw 0 (x_T of the throughput mode).
 template <class Op>
-__global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__ xs, typename Op::elem_t* xs_op,
-                                long xs_op_ps, int B, int F, int T, int XK, int philox, unsigned long long seed,
+__global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__ xs, typename Op::elem_t* xs_op, int B, int F, int T, int XK, int philox, unsigned long long seed,
                                 long long clip_base) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b*T + tau) * (XK/8) + cg
   const int CG = XK / 8;
@@ -28,7 +27,7 @@ __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__
   float* p = xs + (long)bt * XK + cg * 8;
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  Op::template store<8>(xs_op, xs_op_ps, (long)bt * XK + cg * 8, v);
+  Op::template store<8>(xs_op, (long)bt * XK + cg * 8, v);
 }
 
 // frame-major state -> (B, F, 1, T)
@@ -43,7 +42,7 @@ __global__ void state_out_kernel(const float* __restrict__ xs, float* __restrict
 // R trunk input operand: [B*T][XK] = [x_in (F) | h2o (Hd) | zero pad]
 template <class Op>
 __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __restrict__ h2o,
-                                 typename Op::elem_t* xs_op, long xs_op_ps, int BT, int F, int Hd, int XK) {
+                                 typename Op::elem_t* xs_op, int BT, int F, int Hd, int XK) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int CG = XK / 8;
   if (idx >= BT * CG) return;
@@ -57,13 +56,13 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
     else if (c < F + Hd) val = h2o[(long)bt * Hd + (c - F)];
     v[j] = val;
   }
-  Op::template store<8>(xs_op, xs_op_ps, (long)bt * XK + cg * 8, v);
+  Op::template store<8>(xs_op, (long)bt * XK + cg * 8, v);
 }
 
 // Rows the encoder input needs besides the frame tokens, every step: prefix row 0 = timestep-embedding table
 // row of the clip's current t (G), prefix rows 1.. = step-invariant tokens, pad rows [S, Sp) = 0.
 template <class Op>
-__global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* Xop, long xop_ps,
+__global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* Xop,
                                    const float* __restrict__ temb, const int* __restrict__ tcur,
                                    const float* __restrict__ pstatic, int B, int d, int P, int has_t, int S, int Sp) {
   const int rows_per_clip = P + (Sp - S);
@@ -89,7 +88,7 @@ __global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* X
   const long o = ((long)b * Sp + s) * d + cg * 8;
   *(float4*)(X + o) = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(X + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  Op::template store<8>(Xop, xop_ps, o, v);
+  Op::template store<8>(Xop, o, v);
 }
 
 __global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B) {
@@ -144,8 +143,7 @@ __global__ void hand_side_kernel(const unsigned char* __restrict__ side, const f
 
 // fp32 [R][C] -> operand planes [NP][R][ldo] (cols >= C zero-filled up to ldo)
 template <class Op>
-__global__ void pack_operand_kernel(const float* __restrict__ in, typename Op::elem_t* out, long out_ps, long R, int C,
-                                    int ldo) {
+__global__ void pack_operand_kernel(const float* __restrict__ in, typename Op::elem_t* out, long R, int C, int ldo) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int CG = ldo / 8;
   if (idx >= R * CG) return;
@@ -157,14 +155,13 @@ __global__ void pack_operand_kernel(const float* __restrict__ in, typename Op::e
     const int c = cg * 8 + j;
     v[j] = c < C ? in[r * C + c] : 0.f;
   }
-  Op::template store<8>(out, out_ps, r * ldo + cg * 8, v);
+  Op::template store<8>(out, r * ldo + cg * 8, v);
 }
 
 // test hook: packed [B][S][3*H*hd] fp32 -> QK operand [B*Sp][2d] (Q scaled) and V^T operand
 template <class Op>
-__global__ void qkv_pack_kernel(const float* __restrict__ qkv, typename Op::elem_t* qk, long qk_ps,
-                                typename Op::elem_t* vt, long vt_ps, int B, int S, int Sp, int Skp, int H, int hd,
-                                float qscale) {
+__global__ void qkv_pack_kernel(const float* __restrict__ qkv, typename Op::elem_t* qk, typename Op::elem_t* vt, int B, int S,
+                                int Sp, int Skp, int H, int hd, float qscale) {
   const int d = H * hd;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * Sp * 3 * d) return;
@@ -173,45 +170,22 @@ __global__ void qkv_pack_kernel(const float* __restrict__ qkv, typename Op::elem
   const int s = (int)(bs % Sp), b = (int)(bs / Sp);
   float v = 0.f;
   if (s < S) v = qkv[((long)b * S + s) * 3 * d + c];
-  float one[2] = {v, 0.f};
   if (c < 2 * d) {
-    if (c < d) one[0] = v * qscale;
-    // store a single element per plane
-    if constexpr (Op::EB == 4) {
-      ((float*)qk)[bs * 2 * d + c] = one[0];
-    } else {
-      const uint32_t hi = f2bf(one[0]);
-      ((uint16_t*)qk)[bs * 2 * d + c] = (uint16_t)hi;
-      if constexpr (Op::NP == 2) ((uint16_t*)qk)[qk_ps + bs * 2 * d + c] = (uint16_t)f2bf(one[0] - bf2f(hi));
-    }
+    Op::store1(qk, bs * 2 * d + c, c < d ? v * qscale : v);
   } else {
     const int eg = c - 2 * d, h = eg / hd, e = eg % hd;
-    const long o = ((long)(b * H + h) * hd + e) * Skp + s;
-    if constexpr (Op::EB == 4) {
-      ((float*)vt)[o] = v;
-    } else {
-      const uint32_t hi = f2bf(v);
-      ((uint16_t*)vt)[o] = (uint16_t)hi;
-      if constexpr (Op::NP == 2) ((uint16_t*)vt)[vt_ps + o] = (uint16_t)f2bf(v - bf2f(hi));
-    }
+    Op::store1(vt, ((long)(b * H + h) * hd + e) * Skp + s, v);
   }
 }
 
-// operand planes [NP][R][ld] -> fp32 (test hook; x3: hi + lo)
+// operand [R][ld] -> fp32 (test hook)
 template <class Op>
-__global__ void unpack_operand_kernel(const typename Op::elem_t* in, long in_ps, float* __restrict__ out, long R, int C,
-                                      int ld) {
+__global__ void unpack_operand_kernel(const typename Op::elem_t* in, float* __restrict__ out, long R, int C, int ld) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * C) return;
   const int c = (int)(idx % C);
   const long r = idx / C;
-  if constexpr (Op::EB == 4) {
-    out[idx] = ((const float*)in)[r * ld + c];
-  } else {
-    float v = bf2f(((const uint16_t*)in)[r * ld + c]);
-    if constexpr (Op::NP == 2) v += bf2f(((const uint16_t*)in)[in_ps + r * ld + c]);
-    out[idx] = v;
-  }
+  out[idx] = Op::load1(in, r * ld + c);
 }
 
 // x_{t-1} = coef1 x0 + coef2 x_t + [t != 0] sigma eps   (standalone form of the fused update)
