@@ -2,7 +2,8 @@
 // (clip, head); interaction_segment_mdm.py:63-70,171 -> nn.MultiheadAttention).
 //
 // Workgroup = NW waves = NW tiles of 16 queries of one (clip, head); keys/values are streamed through LDS in
-// blocks of 32 keys with an online softmax, so LDS and registers are bounded for every arithmetic mode.
+// blocks of 32 keys (LDS-DMA, double-buffered: block kb+1 is in flight while block kb is multiplied) with an
+// online softmax, so LDS and registers are bounded for every arithmetic mode.
 // Both products run "swapped" so that the softmax axis (keys) lies along the MFMA row index and each lane owns
 // one query column:
 //     S^T[key][query] = K . Q^T      A operand = K rows from LDS (swizzled, ds_read_b128), B operand = Q (registers)
@@ -27,12 +28,14 @@ struct AttnCfg {
   static constexpr int KROWB = HD * EB;   // bytes per K row (one head)
   static constexpr int KG = KROWB / 128;  // 128-byte groups per K row
   static constexpr int VROWB = 32 * EB;   // bytes of one V^T row block (32 keys): 64 (bf16) / 128 (f32, bf16x3)
-  // LDS stride of a V^T row: bf16 and bf16x3 are read with 8-byte accesses and padded (conflict-free per
-  // tools/lds_bank_sim.py); f32 is read with ds_read_b128 and XOR-swizzled like a GEMM tile row
-  static constexpr int VSTR = (Op::PREC == 1) ? 80 : (Op::PREC == 2 ? 144 : 128);
+  // V^T rows are stored unpadded (LDS-DMA writes linearly) with their 16-byte chunks XOR-swizzled by the row:
+  // 128-byte rows like a GEMM tile row ((e >> 1) & 7), 64-byte rows by swz_chunk<64> - conflict-free for the
+  // ds_read_b128 fragment reads (tools/lds_bank_sim.py)
+  static constexpr int VSTR = VROWB;
   static constexpr int K_BYTES = 32 * KROWB;
   static constexpr int V_BYTES = HD * VSTR;
-  static constexpr int SMEM = K_BYTES + V_BYTES;
+  static constexpr int STAGE = K_BYTES + V_BYTES;
+  static constexpr int SMEM = 2 * STAGE;
   static_assert(KROWB % 128 == 0, "head slice must be whole 128-byte groups");
 };
 
@@ -42,11 +45,10 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
   constexpr int EB = Op::EB, KG = C::KG;
   constexpr int NT16 = HD / 16;  // output tiles along e
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + C::K_BYTES;
 
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int lane = tid & 63, nw = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / aa.H, h = bh % aa.H;
   const int q0 = (blockIdx.x * nw + wave) * 16;
@@ -75,32 +77,44 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
   const int nkb = (S + 31) / 32;
   constexpr int KCH = C::KROWB / 16;  // chunks per K row
   constexpr int VCH = C::VROWB / 16;  // chunks per V^T row block
-  // K-row swizzle: 128-byte rows use the GEMM tile swizzle, longer rows XOR the low 4 chunk bits with the row
+  // chunk swizzles (involutions): K rows of 128 bytes use the GEMM tile swizzle, longer K rows XOR the low 4 chunk
+  // bits with the row; V^T rows see the comment at AttnCfg::VSTR
   auto kswz = [](int ch, int row) -> int {
     if constexpr (C::KROWB >= 256) return (ch & ~15) | ((ch ^ row) & 15);
     else return ch ^ ((row >> 1) & 7);
   };
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();  // everyone is done reading the previous block
-    // ---- stage K block: 32 keys x KROWB bytes (rows past the clip are clamped; they are masked below)
-    for (int q = tid; q < 32 * KCH; q += nthr) {
-      const int r = q / KCH, ch = q % KCH;
+  auto vswz = [](int ch, int e) -> int {
+    if constexpr (C::VROWB == 128) return ch ^ ((e >> 1) & 7);
+    else return ch ^ swz_chunk<64>(e);
+  };
+  // LDS-DMA pieces (1 KiB = 64 lanes x 16 B, linear in LDS; the swizzle goes on each lane's SOURCE chunk)
+  constexpr int K_RPP = 1024 / C::KROWB, K_PIECES = C::K_BYTES / 1024;  // K rows per piece
+  constexpr int V_RPP = 1024 / C::VROWB, V_PIECES = C::V_BYTES / 1024;
+  const char* kbase = (const char*)aa.qk + (row_base * (2 * d) + d + h * HD) * EB;
+  const char* vbase = (const char*)aa.vt + ((long)bh * HD) * aa.Skp * EB;
+  auto issue_block = [&](int kb, int stage) {
+    char* st = smem + stage * C::STAGE;
+    for (int q = wave; q < K_PIECES; q += nw) {
+      const int r = q * K_RPP + lane / KCH, pc = lane % KCH;
       int key = kb * 32 + r;
-      key = key < Sp ? key : Sp - 1;
-      const int4 v = *(const int4*)((const char*)aa.qk + ((row_base + key) * (2 * d) + d + h * HD) * EB + ch * 16);
-      *(int4*)(Ks + r * C::KROWB + kswz(ch, r) * 16) = v;
+      key = key < Sp ? key : Sp - 1;  // rows past the clip are clamped; they are masked below
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)key * (2 * d) * EB + kswz(pc, r) * 16),
+                                       (__attribute__((address_space(3))) void*)(st + q * 1024), 16, 0, 0);
     }
-    // ---- stage V^T block: HD rows x 32 keys
-    for (int q = tid; q < HD * VCH; q += nthr) {
-      const int e = q / VCH, ch = q % VCH;
-      const int4 v = *(const int4*)((const char*)aa.vt + (((long)bh * HD + e) * aa.Skp + kb * 32) * EB + ch * 16);
-      int sch = ch;
-      if constexpr (Op::PREC == 0) sch = ch ^ ((e >> 1) & 7);
-      *(int4*)(Vs + e * C::VSTR + sch * 16) = v;
+    for (int q = wave; q < V_PIECES; q += nw) {
+      const int e = q * V_RPP + lane / VCH, pc = lane % VCH;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long)e * aa.Skp + kb * 32) * EB + vswz(pc, e) * 16),
+                                       (__attribute__((address_space(3))) void*)(st + C::K_BYTES + q * 1024), 16, 0, 0);
     }
-    __syncthreads();
-    if (!active) continue;
+  };
+
+  issue_block(0, 0);
+  __syncthreads();
+  for (int kb = 0; kb < nkb; ++kb) {
+    const char* Ks = smem + (kb & 1) * C::STAGE;
+    const char* Vs = Ks + C::K_BYTES;
+    if (kb + 1 < nkb) issue_block(kb + 1, (kb + 1) & 1);
+    if (active) {
 
     // ---- S^T tiles: keys 16t + 4g + reg, query lr
     f32x4 st[2];
@@ -117,15 +131,15 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
       }
     }
     // ---- mask + online softmax (per query = per lane column; the 4 lane groups hold disjoint keys)
-    float bm = -1e30f;
+    if (kb == nkb - 1) {  // only the last block can contain keys >= S
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb * 32 + t * 16 + 4 * g + r;
-        if (key >= S) st[t][r] = -1e30f;
-        bm = fmaxf(bm, st[t][r]);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (kb * 32 + t * 16 + 4 * g + r >= S) st[t][r] = -1e30f;
+    }
+    float bm = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                     fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
     bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
     const float m_new = fmaxf(m_run, bm);
@@ -153,8 +167,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
         const int e = nt * 16 + lr;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int ch = (t * 4 + g) ^ ((e >> 1) & 7);
-          const int4 vf = *(const int4*)(Vs + e * C::VSTR + ch * 16);
+          const int4 vf = *(const int4*)(Vs + e * C::VSTR + vswz(t * 4 + g, e) * 16);
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vf.x), st[t][0], o[nt], 0, 0, 0);
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vf.y), st[t][1], o[nt], 0, 0, 0);
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vf.z), st[t][2], o[nt], 0, 0, 0);
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
       }
     } else {
       // bf16: B fragment element j of lane group g is P[key 4g + j] (j < 4) / P[key 16 + 4g + j - 4] (j >= 4);
-      // the V^T A fragment is read with the same key permutation (two 8-byte reads per plane).
+      // V^T is stored with exactly that key order, so its A fragment is one 16-byte chunk per plane.
       uint32_t hi[8];
       float lo[8];
 #pragma unroll
@@ -184,20 +197,19 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT16; ++nt) {
-        const char* vp = Vs + (nt * 16 + lr) * C::VSTR + 8 * g;
-        const int2 a0 = *(const int2*)vp;
-        const int2 a1 = *(const int2*)(vp + 32);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_int4(a0.x, a0.y, a1.x, a1.y));
+        // V^T is stored key-permuted (vt_key_pos): the fragment of lane group g is chunk g (hi) / 4 + g (lo) of row e
+        const int e = nt * 16 + lr;
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, *(const int4*)(Vs + e * C::VSTR + vswz(g, e) * 16));
         if constexpr (Op::PREC == 2) {
-          const int2 b0 = *(const int2*)(vp + 64);
-          const int2 b1 = *(const int2*)(vp + 96);
-          const bf16x8 vl = __builtin_bit_cast(bf16x8, make_int4(b0.x, b0.y, b1.x, b1.y));
+          const bf16x8 vl = __builtin_bit_cast(bf16x8, *(const int4*)(Vs + e * C::VSTR + vswz(4 + g, e) * 16));
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[nt], 0, 0, 0);
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[nt], 0, 0, 0);
         }
         o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[nt], 0, 0, 0);
       }
     }
+    }  // active
+    __syncthreads();  // block kb+1 has landed (vmcnt(0) + barrier) and everyone is done reading block kb
   }
 
   if (!active) return;

@@ -185,6 +185,17 @@ struct OpBF16X3 {
   }
 };
 
+// Position of key k inside a V^T row.  The P.V product takes P straight from the S^T accumulator layout, in which
+// lane group g of a 32-key block holds keys {4g..4g+3} and {16+4g..16+4g+3}; for the bf16 modes V^T is therefore stored
+// with those 8 keys adjacent (position 8g + 4*(k>>4 & 1) + (k & 3) inside the block), so that the V^T fragment of
+// lane group g is the plain 16-byte chunk g of the row group - one ds_read_b128, same addressing as a GEMM fragment.
+// f32 MFMAs consume one key per lane group per instruction and keep the natural order.
+template <class Op>
+TAMF_DEV int vt_key_pos(int k) {
+  if constexpr (Op::PREC == 0) return k;
+  else return (k & ~31) | (((k & 15) >> 2) << 3) | (((k >> 4) & 1) << 2) | (k & 3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------

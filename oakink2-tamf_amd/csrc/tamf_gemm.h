@@ -145,7 +145,13 @@ struct EpiQKV {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Ct[(rg * 8 + j) * LDC + col] + bb;
-        Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
+        const long rowb = ((long)(b * H + h) * hd + e) * Skp;
+        if constexpr (Op::PREC == 0) {
+          Op::template store<8>(vt, rowb + s0, v);
+        } else {  // keys s0..s0+3 and s0+4..s0+7 belong to two lane groups of the P.V fragment (vt_key_pos)
+          Op::template store<4>(vt, rowb + vt_key_pos<Op>(s0), v);
+          Op::template store<4>(vt, rowb + vt_key_pos<Op>(s0 + 4), v + 4);
+        }
       }
     }
   }

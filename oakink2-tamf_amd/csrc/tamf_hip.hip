@@ -236,13 +236,19 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               AttnCfg<Op, 128>::SMEM)) != hipSuccess) return e;
   return hipSuccess;
 }
 
 template <class Op>
 static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
   const int nqt = (aa.Sp + 15) / 16;
-  const int chunks = (nqt + 7) / 8;
+  static const int nw_env = []() { const char* e = getenv("TAMF_ATTN_NW"); return e ? atoi(e) : 0; }();
+  const int nw_max = (nw_env >= 1 && nw_env <= 8) ? nw_env : 8;
+  const int chunks = (nqt + nw_max - 1) / nw_max;
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
   constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;

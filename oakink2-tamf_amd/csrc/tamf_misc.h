@@ -174,7 +174,7 @@ __global__ void qkv_pack_kernel(const float* __restrict__ qkv, typename Op::elem
     Op::store1(qk, bs * 2 * d + c, c < d ? v * qscale : v);
   } else {
     const int eg = c - 2 * d, h = eg / hd, e = eg % hd;
-    Op::store1(vt, ((long)(b * H + h) * hd + e) * Skp + s, v);
+    Op::store1(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s), v);
   }
 }
 
