@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile of one step here (json)")
+    ap.add_argument("--also", default="bf16", help="comma list of extra dtypes measured with 1 loop each (reported under other_dtypes); '' = none")
     args = ap.parse_args()
 
     import numpy as np
@@ -208,6 +209,26 @@ def main():
             with open(args.profile_out, "w") as f:
                 json.dump({"dtype": args.dtype, "B": B, "T": T, "step_ms_eventsum": step_ms, "kernels": prof_rows}, f, indent=1)
 
+    # secondary dtypes: one warm-up + one timed loop each on rank 0's shard only (context, not the headline)
+    other = {}
+    if rank == 0 and world == 1:
+        for dt in [d for d in args.also.split(",") if d and d != args.dtype]:
+            c2 = TamfContext(arch, B, T, precision=dt, device=dev)
+            c2.load_state_dict(sd, max_timesteps=max(N, 1000))
+            c2.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+            c2.set_cond(cond_dev["text_embedding"], cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"],
+                        cond_dev["obj_traj"])
+            c2.sample_loop(noise=None, seed=1, clip_id_base=clip0, out=out)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            c2.sample_loop(noise=None, seed=2, clip_id_base=clip0, out=out)
+            torch.cuda.synchronize(dev)
+            dt_s = time.perf_counter() - t1
+            other[dt] = {"value": B * T / dt_s, "unit": "frames/s", "ms_per_ddpm_step": dt_s / N * 1e3,
+                         "whole_path_tflops": flops_per_clip_step(arch, T) * B * N / dt_s / 1e12,
+                         "note": "same workload, 1 timed loop; max |err| vs reference in DESIGN.md section 2"}
+            c2.close()
+
     if rank == 0:
         frames = world * B * T * args.steps
         value = frames / elapsed
@@ -243,6 +264,8 @@ def main():
             "finite": finite,
             "roofline": roofline,
         }
+        if other:
+            line["other_dtypes"] = other
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -76,6 +76,7 @@ struct tamf_ctx {
   // activations
   int B = 0, T = 0, S = 0, Sp = 0, Skp = 0, M = 0;
   long Mmax = 0;
+  float* tmp32 = nullptr;  // [M][d] fp32 scratch of the two-kernel FFN2 form
   float *xs = nullptr, *cobj = nullptr, *X = nullptr, *pstatic = nullptr, *etmp = nullptr, *meanbuf = nullptr,
         *objfeat = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
@@ -183,6 +184,13 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // 128 x 128 tiles do not (it costs them 5-8 %).  TAMF_GEMM_KROT / tamf_set_gemm_tuning override both.
 static int g_krot = []() {
   const char* e = getenv("TAMF_GEMM_KROT");
+  return e ? atoi(e) : -1;
+}();
+// FFN2 (K = ff) as one LayerNorm-fused 64 x d GEMM (0) or as a 128 x 128-tile GEMM + row-wise LayerNorm kernel (1).
+// -1 = default: two kernels in bf16x3 (139 -> 106 + 21 us in situ: the 64 x d tile streams the whole 4 MB split weight
+// panel through every CU), fused otherwise (bf16: 69 vs 52 + 19 us).  TAMF_FFN2_TWO_KERNEL overrides.
+static int g_ffn2_two_kernel = []() {
+  const char* e = getenv("TAMF_FFN2_TWO_KERNEL");
   return e ? atoi(e) : -1;
 }();
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
@@ -345,6 +353,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   A(alloc_operand(ctx, &ctx->Vt_op, (long)max_batch * d * Skpmax, true));
   A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
   A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
+  A(dev_alloc(ctx, (void**)&ctx->tmp32, Mmax * d * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
   const long meansz = std::max<long>((long)max_batch * std::max(arch->obj_embed_dim, arch->hand_shape_dim),
@@ -690,9 +699,22 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f};
-      HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
-      mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
+      if ((g_ffn2_two_kernel < 0 ? Op::PREC == 2 : g_ffn2_two_kernel != 0) && ctx->tmp32) {
+        // 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
+        EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
+        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+        mark("gemm_ffn2", BS * 2.0 * dd * ff);
+        const int rows_per_blk = 4;
+        dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
+        if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+        else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+        else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+        mark("ffn2_residual_ln", 0.0);
+      } else {
+        EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f};
+        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+        mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
+      }
     }
   }
   {

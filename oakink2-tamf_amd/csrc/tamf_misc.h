@@ -91,6 +91,40 @@ __global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* X
   Op::template store<8>(Xop, o, v);
 }
 
+// y = LayerNorm(resid + c) * gamma + beta, one wave per row of D = 64 * VPL columns; writes fp32 + operand
+// (second half of the two-kernel form of a LayerNorm-fused GEMM: tamf_hip.hip, FFN2)
+template <class Op, int VPL>
+__global__ void residual_ln_kernel(const float* __restrict__ c, const float* resid, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* xout, typename Op::elem_t* xop, int M,
+                                   float eps) {
+  constexpr int D = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int c0 = lane * VPL;
+  float v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    v[j] = c[(long)row * D + c0 + j] + resid[(long)row * D + c0 + j];
+    s += v[j];
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float dl = v[j] - mean;
+    q += dl * dl;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    v[j] = (v[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+    xout[(long)row * D + c0 + j] = v[j];
+  }
+  Op::template store<VPL>(xop, (long)row * D + c0, v);
+}
+
 __global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) tcur[i] = t_dev ? (int)t_dev[i] : uniform_t;
