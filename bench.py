@@ -40,6 +40,21 @@ def flops_per_clip_step(arch, T):
     return L * S * (8 * d * d + 4 * d * ff + 4 * S * d) + T * (4 * 99 * d + 6 * d * d) + 4 * d * d
 
 
+def hbm_traffic(dtype, kernel, B, T):
+    """HBM-side bytes per launch of `kernel` from the committed PMC measurement of this exact workload
+    (profiles/r01/hbm_traffic_<dtype>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
+    per the gfx950 correction of MI355X_MICROARCH.md).  None when no measurement matches."""
+    path = os.path.join(ROOT, "profiles", "r01", f"hbm_traffic_{dtype}.json")
+    try:
+        with open(path) as f:
+            m = json.load(f)
+        if m.get("B") == B and m.get("T") == T and kernel in m["kernels"]:
+            return m["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota
     (the GPU box exposes 256 logical CPUs but grants a 16-CPU quota; oversubscribing it is 20x slower)."""
@@ -201,7 +216,7 @@ def main():
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": dom["tflops"] / peak,
-            "traffic": None,
+            "traffic": hbm_traffic(args.dtype, dom["kernel"], B, T),
             "avg_launch_ms": dom["avg_ms"],
             "share_of_step": dom["share"],
         }
