@@ -125,6 +125,21 @@ int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64
 int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
                 void* stream);
 
+/* ---- geometry either side of the trunks ---------------------------- */
+/* Pose decode of launch/sample_refine.py:254-260 / model/segment_refine_model.py:117-124:
+ * pose_repr (n_frames, 3 + 6*n_joints) f32 -> tsl (n_frames, 3) [may be NULL] and unit quaternions
+ * (n_frames, n_joints, 4) in (w, x, y, z) order with w >= 0 (dev_fn/transform/rotation.py:446-467,167-213,24-35). */
+int tamf_pose_decode(const float* pose_repr_dev, int64_t n_frames, int32_t n_joints, float* tsl_out_dev,
+                     float* quat_out_dev, void* stream);
+/* Hand->object distance feature of SegmentRefineModel.multi_object_h2o_dist (model/segment_refine_model.py:142-168,
+ * model/loss/chamfer_distance.py:4-64 with y_normals = None; replaces the external chamfer_distance CUDA extension):
+ *   h2o[b,t,v] = min_{o < obj_num[b], j < P} || hand_verts[b,t,v] - (R(b,o,t) obj_points[b,o,j] + tsl(b,o,t)) ||_2
+ * hand_verts (B,T,V,3), obj_traj (B,nobj,T,9) = [tsl | rot6d], obj_points (B,nobj,P,3) in the object frame,
+ * obj_num (B,) int32 device or NULL (= nobj for every clip), out (B,T,V); V <= 1024. */
+int tamf_h2o_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                  const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
+                  float* h2o_out_dev, void* stream);
+
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);
 /* Runs ONE denoiser step (DDPM update at t = n_steps/2, Philox noise; the sampler state is advanced by it) kernel by

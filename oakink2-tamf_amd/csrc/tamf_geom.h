@@ -1,0 +1,120 @@
+// Geometry kernels either side of the trunks: pose decode (rot6d -> rotation matrix ->
+// unit quaternion) and the hand-vertex -> nearest object point distance feature of the refiner.  fp32, VALU-bound.
+#pragma once
+#include "tamf_device.h"
+
+TAMF_DEV void gs_rows(const float* a, float (&r)[9]) {
+  // Gram-Schmidt of (a[0..2], a[3..5]); rows of the rotation matrix = b1, b2, b1 x b2
+  // (dev_fn/transform/rotation.py:446-467; F.normalize: v / max(||v||, 1e-12))
+  const float n1 = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
+  const float b1x = a[0] / n1, b1y = a[1] / n1, b1z = a[2] / n1;
+  const float dp = b1x * a[3] + b1y * a[4] + b1z * a[5];
+  float b2x = a[3] - dp * b1x, b2y = a[4] - dp * b1y, b2z = a[5] - dp * b1z;
+  const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+  b2x /= n2; b2y /= n2; b2z /= n2;
+  r[0] = b1x; r[1] = b1y; r[2] = b1z;
+  r[3] = b2x; r[4] = b2y; r[5] = b2z;
+  r[6] = b1y * b2z - b1z * b2y;
+  r[7] = b1z * b2x - b1x * b2z;
+  r[8] = b1x * b2y - b1y * b2x;
+}
+
+// pose_repr (N, F) with F = 3 + 6*J  ->  tsl (N, 3), quat (N, J, 4) in (w, x, y, z) with w >= 0
+// (oakink2_tamf/launch/sample_refine.py:254-260; rotation.py:167-213 rotmat_to_quat, :24-35 standardize_quat)
+__global__ void pose_decode_kernel(const float* __restrict__ pose, float* __restrict__ tsl, float* __restrict__ quat, long N,
+                                   int J, int F) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * J) return;
+  const int j = (int)(idx % J);
+  const long n = idx / J;
+  const float* p = pose + n * F;
+  if (j == 0 && tsl) {
+    tsl[n * 3 + 0] = p[0];
+    tsl[n * 3 + 1] = p[1];
+    tsl[n * 3 + 2] = p[2];
+  }
+  float a[6], m[9];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a[k] = p[3 + j * 6 + k];
+  gs_rows(a, m);
+  const float s0 = 1.0f + m[0] + m[4] + m[8], s1 = 1.0f + m[0] - m[4] - m[8];
+  const float s2 = 1.0f - m[0] + m[4] - m[8], s3 = 1.0f - m[0] - m[4] + m[8];
+  const float q0 = s0 > 0.f ? sqrtf(s0) : 0.f, q1 = s1 > 0.f ? sqrtf(s1) : 0.f;
+  const float q2 = s2 > 0.f ? sqrtf(s2) : 0.f, q3 = s3 > 0.f ? sqrtf(s3) : 0.f;
+  // argmax (first maximum, as torch.argmax) picks the best-conditioned candidate
+  int best = 0;
+  float qb = q0;
+  if (q1 > qb) { qb = q1; best = 1; }
+  if (q2 > qb) { qb = q2; best = 2; }
+  if (q3 > qb) { qb = q3; best = 3; }
+  float c[4];
+  if (best == 0) { c[0] = q0 * q0; c[1] = m[7] - m[5]; c[2] = m[2] - m[6]; c[3] = m[3] - m[1]; }
+  else if (best == 1) { c[0] = m[7] - m[5]; c[1] = q1 * q1; c[2] = m[3] + m[1]; c[3] = m[2] + m[6]; }
+  else if (best == 2) { c[0] = m[2] - m[6]; c[1] = m[3] + m[1]; c[2] = q2 * q2; c[3] = m[5] + m[7]; }
+  else { c[0] = m[3] - m[1]; c[1] = m[6] + m[2]; c[2] = m[7] + m[5]; c[3] = q3 * q3; }
+  const float den = 2.0f * fmaxf(qb, 0.1f);
+  float w = c[0] / den, x = c[1] / den, y = c[2] / den, z = c[3] / den;
+  if (w < 0.f) { w = -w; x = -x; y = -y; z = -z; }
+  float* o = quat + idx * 4;
+  o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+
+// h2o[b, t, v] = min over real objects o and points j of || hand[b,t,v] - (R(b,o,t) pts[b,o,j] + tsl(b,o,t)) ||
+// (oakink2_tamf/model/segment_refine_model.py:142-168, model/loss/chamfer_distance.py:4-64 with y_normals = None).
+// One workgroup per (t, b): every thread keeps up to 4 hand vertices in registers; object points are transformed to
+// the frame's pose on the fly and streamed through LDS in tiles of 256, read back as 16-byte broadcasts.
+constexpr int H2O_VPT = 4;
+__global__ __launch_bounds__(256) void h2o_dist_kernel(const float* __restrict__ hand, const float* __restrict__ traj,
+                                                       const float* __restrict__ pts, const int* __restrict__ obj_num,
+                                                       float* __restrict__ out, int T, int V, int nobj, int P) {
+  __shared__ float4 tile[256];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* hv = hand + ((long)b * T + t) * V * 3;
+  float vx[H2O_VPT], vy[H2O_VPT], vz[H2O_VPT], best[H2O_VPT];
+#pragma unroll
+  for (int i = 0; i < H2O_VPT; ++i) {
+    const int v = tid + 256 * i;
+    const bool ok = v < V;
+    vx[i] = ok ? hv[v * 3 + 0] : 0.f;
+    vy[i] = ok ? hv[v * 3 + 1] : 0.f;
+    vz[i] = ok ? hv[v * 3 + 2] : 0.f;
+    best[i] = 3.0e38f;
+  }
+  const int n = obj_num ? min(obj_num[b], nobj) : nobj;
+  for (int o = 0; o < n; ++o) {
+    const float* tr = traj + (((long)b * nobj + o) * T + t) * 9;
+    float a[6], R[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = tr[3 + k];
+    gs_rows(a, R);
+    const float tx = tr[0], ty = tr[1], tz = tr[2];
+    const float* pp = pts + ((long)b * nobj + o) * P * 3;
+    for (int p0 = 0; p0 < P; p0 += 256) {
+      const int j = p0 + tid;
+      float4 q = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // padding point: far away, never the minimum
+      if (j < P) {
+        const float px = pp[j * 3 + 0], py = pp[j * 3 + 1], pz = pp[j * 3 + 2];
+        q.x = fmaf(R[2], pz, fmaf(R[1], py, R[0] * px)) + tx;
+        q.y = fmaf(R[5], pz, fmaf(R[4], py, R[3] * px)) + ty;
+        q.z = fmaf(R[8], pz, fmaf(R[7], py, R[6] * px)) + tz;
+      }
+      __syncthreads();
+      tile[tid] = q;
+      __syncthreads();
+#pragma unroll 8
+      for (int k = 0; k < 256; ++k) {
+        const float4 c = tile[k];
+#pragma unroll
+        for (int i = 0; i < H2O_VPT; ++i) {
+          const float dx = vx[i] - c.x, dy = vy[i] - c.y, dz = vz[i] - c.z;
+          best[i] = fminf(best[i], fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < H2O_VPT; ++i) {
+    const int v = tid + 256 * i;
+    if (v < V) out[((long)b * T + t) * V + v] = sqrtf(best[i]);
+  }
+}

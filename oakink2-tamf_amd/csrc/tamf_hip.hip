@@ -16,6 +16,7 @@
 
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
+#include "tamf_geom.h"
 #include "tamf_misc.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1113,6 +1114,33 @@ extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot
   }
   g_krot = saved_rot;
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry either side of the trunks
+// ------------------------------------------------------------------------------------------------
+extern "C" int tamf_pose_decode(const float* pose_repr_dev, int64_t n_frames, int32_t n_joints, float* tsl_out_dev,
+                                float* quat_out_dev, void* stream) {
+  if (!pose_repr_dev || !quat_out_dev || n_frames <= 0 || n_joints <= 0) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(pose_decode_kernel, grid1d(n_frames * n_joints), dim3(256), 0, (hipStream_t)stream, pose_repr_dev,
+                     tsl_out_dev, quat_out_dev, (long)n_frames, n_joints, 3 + 6 * n_joints);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int tamf_h2o_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                             const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
+                             float* h2o_out_dev, void* stream) {
+  if (!hand_verts_dev || !obj_traj_dev || !obj_points_dev || !h2o_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  if (B <= 0 || T <= 0 || V <= 0 || nobj <= 0 || P <= 0) return fail(nullptr, TAMF_ERR_INVALID, "bad shape");
+  if (V > 256 * H2O_VPT) return fail(nullptr, TAMF_ERR_INVALID, "at most 1024 hand vertices per frame (MANO has 778)");
+  if (B > 65535) return fail(nullptr, TAMF_ERR_INVALID, "batch too large for one launch");
+  hipLaunchKernelGGL(h2o_dist_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, hand_verts_dev, obj_traj_dev,
+                     obj_points_dev, (const int*)obj_num_dev, h2o_out_dev, T, V, nobj, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
 }
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {

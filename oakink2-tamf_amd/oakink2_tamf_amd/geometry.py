@@ -1,0 +1,60 @@
+"""HIP versions of the geometry steps around the trunks.
+
+pose_repr_to_quat      reference: rot6d_to_rotmat + rotmat_to_quat (dev_fn/transform/rotation.py:446-467,167-213) as used by
+                       launch/sample_refine.py:254-260 and model/segment_refine_model.py:117-124 before the MANO layer
+multi_object_h2o_dist  reference: SegmentRefineModel.multi_object_h2o_dist (model/segment_refine_model.py:142-168) ->
+                       point2point_signed (model/loss/chamfer_distance.py:4-64) -> external chamfer_distance CUDA extension
+Both return torch tensors on the inputs' device; no CPU fallback."""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional, Sequence
+
+import torch
+
+from .hip_backend import _check, _dev_f32, _stream_ptr, lib, require_gpu
+
+
+def _bind():
+    from ctypes import c_int32, c_int64
+
+    L = lib()
+    L.tamf_pose_decode.argtypes = [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
+    L.tamf_h2o_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
+    return L
+
+
+def pose_repr_to_quat(pose_repr: torch.Tensor):
+    """(..., 3 + 6J) -> tsl (..., 3), quat (..., J, 4) (w, x, y, z), w >= 0."""
+    dev = require_gpu(pose_repr.device)
+    p = _dev_f32(pose_repr, dev)
+    F = p.shape[-1]
+    J = (F - 3) // 6
+    assert 3 + 6 * J == F, "pose representation must be 3 + 6*J wide"
+    n = p.numel() // F
+    tsl = torch.empty(p.shape[:-1] + (3,), device=dev, dtype=torch.float32)
+    quat = torch.empty(p.shape[:-1] + (J, 4), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _check(_bind().tamf_pose_decode(c_void_p(p.data_ptr()), n, J, c_void_p(tsl.data_ptr()), c_void_p(quat.data_ptr()),
+                                        c_void_p(_stream_ptr(dev))))
+    return tsl, quat
+
+
+def multi_object_h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor,
+                          obj_num: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """hand_verts (B,T,V,3), obj_traj (B,nobj,T,9), obj_points (B,nobj,P,3), obj_num per clip -> (B,T,V)."""
+    dev = require_gpu(hand_verts.device)
+    hv, tr, pts = _dev_f32(hand_verts, dev), _dev_f32(obj_traj, dev), _dev_f32(obj_points, dev)
+    B, T, V, _ = hv.shape
+    nobj, P = pts.shape[1], pts.shape[2]
+    assert tuple(tr.shape) == (B, nobj, T, 9) and pts.shape[0] == B and pts.shape[3] == 3
+    on = None
+    if obj_num is not None:
+        on = torch.as_tensor(list(obj_num), dtype=torch.int32, device=dev)
+        assert on.numel() == B
+    out = torch.empty((B, T, V), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _check(_bind().tamf_h2o_dist(c_void_p(hv.data_ptr()), c_void_p(tr.data_ptr()), c_void_p(pts.data_ptr()),
+                                     c_void_p(on.data_ptr() if on is not None else 0), B, T, V, nobj, P,
+                                     c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return out

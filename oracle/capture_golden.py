@@ -269,6 +269,56 @@ def capture_refine(name: str, arch: O.Arch, B: int, T: int, nobj=2):
     np.savez_compressed(os.path.join(OUT_DIR, f"refine_{name}.npz"), **fix)
 
 
+def capture_geometry():
+    """Rows 8(f)-1/-2: the reference's own rot6d/quaternion helpers (dev_fn.transform) and its hand->object distance
+    (SegmentRefineModel.multi_object_h2o_dist -> point2point_signed) with a stand-in `chamfer_distance` module that
+    implements the published brute-force nearest-neighbour search (source of the real CUDA extension is absent)."""
+    from dev_fn.transform.rotation import rot6d_to_rotmat, rotmat_to_quat
+    from . import geometry_oracle as G
+
+    chd = types.ModuleType("chamfer_distance")
+
+    class ChamferDistance(torch.nn.Module):
+        def forward(self, x, y):
+            d2 = ((x[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)
+            d1, i1 = d2.min(dim=2)
+            dd2, i2 = d2.min(dim=1)
+            return d1, dd2, i1.int(), i2.int()
+
+    chd.ChamferDistance = ChamferDistance
+    sys.modules["chamfer_distance"] = chd
+    from oakink2_tamf.model.segment_refine_model import SegmentRefineModel
+
+    # pose decode: random poses plus degenerate ones (zero vectors, near-180-degree rotations -> every quaternion branch)
+    N = 64
+    pose = torch.from_numpy(det.det_normal("geom/pose", (N, 99)))
+    pose[0, 3:9] = 0.0
+    pose[1, 3:9] = torch.tensor([1.0, 0, 0, 0, -1.0, 0])   # 180 deg about x
+    pose[2, 3:9] = torch.tensor([-1.0, 0, 0, 0, 1.0, 0])   # 180 deg about y
+    pose[3, 3:9] = torch.tensor([-1.0, 0, 0, 0, -1.0, 0])  # 180 deg about z
+    pose[4, 3:9] = torch.tensor([1.0, 0, 0, 1.0, 0, 0])    # collinear
+    rot6d = pose[:, 3:99].reshape(N, 16, 6)
+    quat = rotmat_to_quat(rot6d_to_rotmat(rot6d))
+    tsl_m, quat_m = G.pose_decode(pose)
+    print(f"pose decode: |ref-oracle| = {(quat - quat_m).abs().max():.3e}")
+
+    # h2o distance: 2 clips, 2 (padded) objects, the second clip has one real object
+    B, T, V, nobj, P = 2, 6, 778, 2, 500
+    hv = torch.from_numpy(det.det_normal("geom/hv", (B, T, V, 3))) * 0.1
+    traj = torch.from_numpy(det.det_normal("geom/traj", (B, nobj, T, 9)))
+    traj[..., 0:3] *= 0.1
+    pts = torch.from_numpy(det.det_normal("geom/pts", (B, nobj, P, 3))) * 0.1
+    obj_num = [2, 1]
+    obj_list = [["a", "b"], ["a"]]
+    ref = SegmentRefineModel.multi_object_h2o_dist(None, hv, torch.zeros_like(hv), obj_list, traj,
+                                                   [pts[b].numpy() for b in range(B)])
+    mine = G.h2o_dist(hv, traj, pts, obj_num)
+    print(f"h2o dist: |ref-oracle| = {(ref - mine).abs().max():.3e}  mean dist {ref.mean():.4f}")
+    np.savez_compressed(os.path.join(OUT_DIR, "geometry.npz"), pose=pose.numpy(), quat=quat.numpy(), hand_verts=hv.numpy(),
+                        obj_traj=traj.numpy(), obj_points=pts.numpy(), obj_num=np.array(obj_num, dtype=np.int32),
+                        h2o=ref.numpy())
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -290,6 +340,7 @@ def main():
     capture_loop("tiny_1000", O.ARCH_TINY, B=2, T=16, steps=1000, store_noise=False)
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
+    capture_geometry()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,79 @@
+"""CPU restatement of the geometry steps either side of the trunks.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Citations relative to /root/reference/src/.
+
+  pose_decode          99-d pose repr -> translation + 16 unit quaternions
+                       (oakink2_tamf/launch/sample_refine.py:254-260, model/segment_refine_model.py:117-124;
+                        dev_fn/transform/rotation.py:446-467 rot6d_to_rotmat, :167-213 rotmat_to_quat, :24-35, :156-164)
+  h2o_dist             hand-vertex -> nearest object point distance feature of R
+                       (oakink2_tamf/model/segment_refine_model.py:142-168 -> model/loss/chamfer_distance.py:4-64 with
+                        y_normals=None: x2y_signed = || x - y[nearest] ||; dev_fn/transform/transform.py:148-154,36-52)
+
+Third-party piece: the nearest-neighbour search itself is `chamfer_distance.ChamferDistance` (otaheri/chamfer_distance,
+un-pinned submodule, source absent): its published algorithm is a brute-force argmin of squared euclidean distances in both
+directions; the golden vectors were captured from the reference's own point2point_signed with a stand-in module implementing
+exactly that (oracle/capture_golden.py:capture_geometry), so the in-tree arithmetic around it is pinned.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def rot6d_to_rotmat(d6: torch.Tensor) -> torch.Tensor:
+    """Gram-Schmidt of the two 3-vectors, rows of the result = b1, b2, b1 x b2 (rotation.py:446-467).
+    F.normalize semantics: v / max(||v||, 1e-12)."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = a1 / a1.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = b2 / b2.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)
+
+
+def rotmat_to_quat(m: torch.Tensor) -> torch.Tensor:
+    """(w, x, y, z) with w >= 0; the best-conditioned of the four candidate formulas (rotation.py:167-213)."""
+    m00, m01, m02 = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    m10, m11, m12 = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    m20, m21, m22 = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    sq = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
+    q_abs = torch.where(sq > 0, torch.sqrt(sq.clamp_min(0)), torch.zeros_like(sq))
+    cand = torch.stack(
+        [
+            torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+            torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+            torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+            torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1),
+        ],
+        dim=-2,
+    )
+    cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = q_abs.argmax(dim=-1)
+    out = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+    return torch.where(out[..., 0:1] < 0, -out, out)
+
+
+def pose_decode(pose_repr: torch.Tensor):
+    """(..., 99) -> tsl (..., 3), quat (..., 16, 4)."""
+    tsl = pose_repr[..., 0:3]
+    rot6d = pose_repr[..., 3:99].reshape(pose_repr.shape[:-1] + (16, 6))
+    return tsl, rotmat_to_quat(rot6d_to_rotmat(rot6d))
+
+
+def h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor, obj_num=None) -> torch.Tensor:
+    """hand_verts (B, T, V, 3); obj_traj (B, nobj, T, 9) = [tsl | rot6d]; obj_points (B, nobj, P, 3) in object frame;
+    obj_num[b] objects of clip b are real.  -> (B, T, V): distance of every hand vertex to its nearest object point
+    after the per-frame rigid transform p -> R p + t."""
+    B, T, V, _ = hand_verts.shape
+    nobj = obj_traj.shape[1]
+    out = torch.empty(B, T, V, dtype=hand_verts.dtype)
+    for b in range(B):
+        n = nobj if obj_num is None else int(obj_num[b])
+        R = rot6d_to_rotmat(obj_traj[b, :n, :, 3:9])  # (n, T, 3, 3)
+        t = obj_traj[b, :n, :, 0:3]  # (n, T, 3)
+        pts = torch.einsum("otij,opj->otpi", R, obj_points[b, :n]) + t[:, :, None, :]  # (n, T, P, 3)
+        pts = pts.permute(1, 0, 2, 3).reshape(T, -1, 3)
+        d2 = ((hand_verts[b][:, :, None, :] - pts[:, None, :, :]) ** 2).sum(-1)  # (T, V, n*P)
+        idx = d2.argmin(dim=-1)
+        near = torch.gather(pts, 1, idx[..., None].expand(T, V, 3))
+        out[b] = (hand_verts[b] - near).norm(dim=-1)
+    return out

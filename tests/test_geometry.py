@@ -1,0 +1,58 @@
+"""Rows 8(f)-1/-2: pose decode and hand->object distance.  CPU: oracle vs the reference's golden outputs.
+GPU: HIP kernels vs the same fixtures (tolerance 2e-6 abs on unit quaternions / 1e-6 abs on distances of ~0.05)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import geometry_oracle as G
+
+
+def test_oracle_pose_decode_matches_reference():
+    fix = load_golden("geometry.npz")
+    tsl, quat = G.pose_decode(torch.from_numpy(fix["pose"]))
+    np.testing.assert_array_equal(tsl.numpy(), fix["pose"][:, :3])
+    np.testing.assert_allclose(quat.numpy(), fix["quat"], rtol=0, atol=1e-7)
+    assert np.allclose(np.linalg.norm(fix["quat"][5:], axis=-1), 1.0, atol=1e-5) and (fix["quat"][..., 0] >= 0).all()
+
+
+def test_oracle_h2o_matches_reference():
+    fix = load_golden("geometry.npz")
+    out = G.h2o_dist(torch.from_numpy(fix["hand_verts"]), torch.from_numpy(fix["obj_traj"]), torch.from_numpy(fix["obj_points"]),
+                     fix["obj_num"])
+    np.testing.assert_allclose(out.numpy(), fix["h2o"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_pose_decode():
+    from oakink2_tamf_amd import geometry
+
+    fix = load_golden("geometry.npz")
+    tsl, quat = geometry.pose_repr_to_quat(torch.from_numpy(fix["pose"]).cuda())
+    np.testing.assert_array_equal(tsl.cpu().numpy(), fix["pose"][:, :3])
+    q, r = quat.cpu().numpy(), fix["quat"]
+    # rows 1-4 are exact 180-degree rotations / degenerate inputs: q and -q describe the same rotation when w == 0
+    err = np.minimum(np.abs(q - r).max(-1), np.abs(q + r).max(-1) + (np.abs(r[..., 0]) > 1e-6) * 1e9)
+    assert err.max() < 2e-6, err.max()
+    # batched shape (B, T, 99)
+    p3 = torch.from_numpy(fix["pose"]).reshape(4, 16, 99).cuda()
+    _, q3 = geometry.pose_repr_to_quat(p3)
+    assert q3.shape == (4, 16, 16, 4) and torch.equal(q3.reshape(64, 16, 4), quat)
+
+
+@pytest.mark.gpu
+def test_hip_h2o_dist():
+    from oakink2_tamf_amd import geometry
+
+    fix = load_golden("geometry.npz")
+    out = geometry.multi_object_h2o_dist(torch.from_numpy(fix["hand_verts"]).cuda(), torch.from_numpy(fix["obj_traj"]).cuda(),
+                                         torch.from_numpy(fix["obj_points"]).cuda(), fix["obj_num"].tolist())
+    np.testing.assert_allclose(out.cpu().numpy(), fix["h2o"], rtol=0, atol=1e-6)
+    # ragged point count (P not a multiple of the 256-point tile) and full object list against the oracle
+    g = torch.Generator().manual_seed(0)
+    hv = torch.randn(1, 3, 778, 3, generator=g) * 0.1
+    tr = torch.randn(1, 3, 3, 9, generator=g)
+    pts = torch.randn(1, 3, 1000, 3, generator=g) * 0.1
+    ref = G.h2o_dist(hv, tr, pts)
+    got = geometry.multi_object_h2o_dist(hv.cuda(), tr.cuda(), pts.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-6)
