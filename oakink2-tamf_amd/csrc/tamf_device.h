@@ -9,21 +9,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define TAMF_DEV __device__ __forceinline__
 
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Register arrays indexed with
-// these constants are promoted to VGPRs by the first SROA pass (runtime-indexed ones wait for loop unrolling and, with
-// scheduling barriers around, ended up in scratch).
-template <int I>
-struct IC {
-  static constexpr int value = I;
-};
-template <int N, int I = 0, class F>
-TAMF_DEV void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(IC<I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
 TAMF_DEV uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
 TAMF_DEV float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
 TAMF_DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
@@ -36,7 +21,6 @@ TAMF_DEV float nan_to_num(float v) {
   if (v == -__builtin_inff()) return -3.4028234663852886e38f;
   return v;
 }
-TAMF_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 TAMF_DEV float silu_exact(float x) { return x / (1.0f + expf(-x)); }
 TAMF_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7 + exp/rcp rounding): ~3x fewer VALU instructions than the

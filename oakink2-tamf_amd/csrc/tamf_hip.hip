@@ -26,7 +26,6 @@ static std::string g_noctx_err;
 
 struct OperandBuf {
   void* p = nullptr;
-  long ps = 0;  // plane stride in elements
 };
 
 struct LayerW {
@@ -150,7 +149,6 @@ static inline float h_bf2f(uint16_t h) {
 // bf16x3 rows are 128-byte groups of 32 elements: [hi: 32 bf16 | lo: 32 bf16] (tamf_device.h "Operand traits").
 static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out) {
   const size_t n = (size_t)N * ldk;
-  out->ps = 0;
   if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
@@ -279,7 +277,6 @@ static inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs
 extern "C" const char* tamf_last_error(const tamf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_noctx_err.c_str(); }
 
 static int alloc_operand(tamf_ctx* ctx, OperandBuf* ob, long elems, bool zero = false) {
-  ob->ps = elems;
   return dev_alloc(ctx, &ob->p, (size_t)elems * ctx->EB, zero);
 }
 
@@ -1082,7 +1079,8 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
       e = gemm128<Op>(ga, ep, st);
     } else {
-      EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
+      static const int bench_act = []() { const char* e = getenv("TAMF_BENCH_ACT"); return e ? atoi(e) : (int)ACT_GELU; }();
+      EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, bench_act};
       e = gemm128<Op>(ga, ep, st);
     }
   }
