@@ -69,10 +69,26 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(arch_name, T, n_ddpm, sample_B=16, timed=2):
+def synthetic_cond(B, T, seed, nobj=2):
+    """Synthetic conditioning of SURVEY.md section 8(d): unit-normal CLIP / object embeddings and trajectories,
+    alternating hand side, per-clip constant betas."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    return {
+        "text_embedding": torch.randn(B, 512, generator=g),
+        "hand_side": ["rh" if b % 2 == 0 else "lh" for b in range(B)],
+        "shape": torch.randn(B, 1, 10, generator=g).repeat(1, T, 1).contiguous(),
+        "obj_embedding": torch.randn(B, nobj, 768, generator=g),
+        "obj_traj": torch.randn(B, nobj, T, 9, generator=g),
+    }
+
+
+def cpu_baseline(arch_name, sd, T, n_ddpm, sample_B=16, timed=2):
     """The oracle (torch-CPU restatement of the reference, proven equal to it on tests/golden) timed on the host
-    cores: a bounded sample of the same workload - `sample_B` clips x (1 warm-up + `timed`) denoiser+DDPM steps -
-    extrapolated to the n_ddpm-step loop (every step does identical work)."""
+    cores with the SAME weights as the GPU run: a bounded sample of the same workload - `sample_B` clips x
+    (1 warm-up + `timed`) denoiser+DDPM steps - extrapolated to the n_ddpm-step loop (every step does identical work).
+    This is the only place bench.py touches oracle/."""
     import torch
 
     from oracle import mdm_oracle as O
@@ -80,8 +96,7 @@ def cpu_baseline(arch_name, T, n_ddpm, sample_B=16, timed=2):
     arch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[arch_name]
     cores = usable_cores()
     torch.set_num_threads(cores)
-    sd = O.det_state_dict(arch, tag="bench/w")
-    cond = O.det_cond(sample_B, T, tag="bench/c", arch=arch)
+    cond = synthetic_cond(sample_B, T, seed=12345)
     tab = O.make_tables(n_ddpm, "cosine")
     g = torch.Generator().manual_seed(0)
     x = torch.randn(sample_B, 99, 1, T, generator=g)
@@ -138,20 +153,22 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from oakink2_tamf_amd.hip_backend import TamfContext
     from oakink2_tamf_amd import shard
-    from oracle import mdm_oracle as O  # synthetic weights / conditioning recipes + cpu_baseline only
+    from oakink2_tamf_amd.hip_backend import TamfContext
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+    from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
 
     arch = ARCHS[args.arch]
-    oarch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[args.arch]
     B, T, N = args.batch, args.frames, args.ddpm_steps
-    sd = O.det_state_dict(oarch, tag="bench/w")
+    # random-init weights of the named architecture (PyTorch default initialisers, fixed seed; identical on all ranks)
+    torch.manual_seed(0)
+    sd = InterationSegmentMDM(**arch).state_dict()
     ctx = TamfContext(arch, B, T, precision=args.dtype, device=dev)
     ctx.load_state_dict(sd, max_timesteps=max(N, 1000))
-    tab = O.make_tables(N, "cosine")
+    tab = create_gaussian_diffusion(diffusion_steps=N, noise_schedule="cosine")
     ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
     clip0 = shard.clip_id_base(rank, B)
-    cond = O.det_cond(B, T, tag=f"bench/c/rank{rank}", arch=oarch)
+    cond = synthetic_cond(B, T, seed=1000 + rank)
     cond_dev = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in cond.items()}
     out = torch.empty(B, 99, 1, T, device=dev)
     gathered = torch.empty(world * B, 99, 1, T, device=dev) if world > 1 else None
@@ -262,7 +279,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic (seed-free deterministic weights/conditioning, device Philox noise)",
+            "data": "synthetic (random-init weights of the named arch, N(0,1) CLIP/object conditioning, device Philox noise)",
             "config": {
                 "workload": f"{args.arch} B={B}/GPU T={T} {N}-step DDPM (BASELINE.json configs[1]); step = one full reverse loop",
                 "clips_per_gpu": B,
@@ -282,7 +299,7 @@ def main():
         if other:
             line["other_dtypes"] = other
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.arch, T, N)
+            line["cpu_baseline"] = cpu_baseline(args.arch, sd, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     ctx.close()

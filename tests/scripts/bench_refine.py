@@ -1,7 +1,7 @@
 """GPU: BASELINE.json configs[3] - arch_refine (MF-MDM R) trunk, B=64, T=196, single forward on cached G samples
 (synthetic here) + the h2o distance feature and the pose decode that surround it.  Reports ms per batch."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
 import torch
 from oakink2_tamf_amd.hip_backend import TamfContext

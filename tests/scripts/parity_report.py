@@ -1,6 +1,6 @@
 """GPU: print max|err| of every golden case for each arithmetic mode (used to state tolerances in DESIGN.md)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 from conftest import golden_cond, load_golden

@@ -1,6 +1,6 @@
 """GPU experiment: one B=64 loop vs two concurrent B=32 loops on two streams (same total clips)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
 import torch
 from oakink2_tamf_amd.hip_backend import TamfContext
