@@ -370,14 +370,23 @@ struct EpiStoreF32 {
 typedef __attribute__((address_space(3))) void tamf_lds_void;
 typedef const __attribute__((address_space(1))) void tamf_gbl_void;
 
+// cache-policy bits of the LDS-DMA loads (compile-time experiment knobs; 0 = default policy)
+#ifndef TAMF_GLDS_AUX_A
+#define TAMF_GLDS_AUX_A 0
+#endif
+#ifndef TAMF_GLDS_AUX_W
+#define TAMF_GLDS_AUX_W 0
+#endif
+template <int AUX>
 TAMF_DEV void glds16(const char* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((tamf_gbl_void*)gsrc, (tamf_lds_void*)lds_wave_base, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((tamf_gbl_void*)gsrc, (tamf_lds_void*)lds_wave_base, 16, 0, AUX);
 }
 
 // logical block id with XCD-contiguous chunks (bijective for any grid size; blocks b and b+8 share an XCD)
 TAMF_DEV int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  const int i = bid >> 3;  // position inside this XCD's chunk, in dispatch order
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
 // waves per SIMD the kernel is built for (LDS admits 2 workgroups per CU for the 128 x 128 tiles, 1 for 64 x 512):
@@ -441,12 +450,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
     _Pragma("unroll") for (int ii = 0; ii < A_PW; ++ii) {                                            \
       const int q_ = wave + ii * NWV;                                                                \
       if (A_PIECES % NWV == 0 || q_ < A_PIECES)                                                      \
-        glds16(Ab + a_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + q_ * 1024);             \
+        glds16<TAMF_GLDS_AUX_A>(Ab + a_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + q_ * 1024);             \
     }                                                                                                \
     _Pragma("unroll") for (int ii = 0; ii < W_PW; ++ii) {                                            \
       const int q_ = wave + ii * NWV;                                                                \
       if (W_PIECES % NWV == 0 || q_ < W_PIECES)                                                      \
-        glds16(Wb + w_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + A_BYTES + q_ * 1024);   \
+        glds16<TAMF_GLDS_AUX_W>(Wb + w_off[ii] + (long)(kt_) * BKB, smem + (s_) * SM::STAGE + A_BYTES + q_ * 1024);   \
     }                                                                                                \
   }
 

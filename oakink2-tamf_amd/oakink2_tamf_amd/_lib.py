@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", tmp, os.path.join(CSRC, "tamf_hip.hip")]
+           "-o", tmp, os.path.join(CSRC, "tamf_hip.hip")] + os.environ.get("TAMF_HIPCC_FLAGS", "").split()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise TamfBuildError("hipcc failed:\n" + res.stdout + res.stderr)
