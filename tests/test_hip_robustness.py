@@ -1,0 +1,111 @@
+"""GPU: robustness of the C-ABI path - odd shapes, re-use of a context across batches, determinism, multiple contexts."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(arch, sd, B, T, prec="f32", n_steps=8):
+    from test_hip_forward import _make_ctx
+
+    return _make_ctx(arch, sd, B, T, prec, n_steps=n_steps)
+
+
+def _cond(B, T, tag, nobj=2):
+    from oracle import mdm_oracle as O
+
+    return O.det_cond(B, T, nobj=nobj, tag=tag, arch=O.ARCH_TINY)
+
+
+@pytest.mark.parametrize("B,T,nobj", [(1, 16, 1), (1, 3, 2), (5, 27, 4), (2, 59, 1), (3, 123, 2)])
+def test_odd_shapes_against_oracle(B, T, nobj):
+    """Sp = round_up(T + 5, 8) and Skp = round_up(T + 5, 32) padding paths, single clip, single frame tile, 4 objects."""
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="rob/w")
+    cond = _cond(B, T, f"rob/{B}/{T}", nobj)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, 99, 1, T, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ref = O.denoiser_forward(sd, arch, x, t, cond)
+    for prec, tol in (("f32", 2e-5), ("bf16x3", 5e-4)):
+        ctx = _ctx(arch, sd, B, T, prec)
+        _set_cond(ctx, cond)
+        out = ctx.denoise(x, t).cpu()
+        assert float((out - ref).abs().max()) < tol, (prec, B, T)
+        ctx.close()
+
+
+def test_context_reuse_smaller_batches_and_determinism():
+    """One context (max B=4, T=32) serves smaller (B, T) batches; the same call twice is bit-identical; the graph is
+    re-captured when the batch shape or the noise source changes."""
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="rob/w")
+    ctx = _ctx(arch, sd, 4, 32, "bf16x3", n_steps=6)
+    tab = O.make_tables(6, "cosine")
+    outs = {}
+    for (B, T) in ((4, 32), (2, 16), (3, 32), (4, 32)):
+        cond = _cond(B, T, f"reuse/{B}/{T}")
+        _set_cond(ctx, cond)
+        a = ctx.sample_loop(noise=None, seed=5, clip_id_base=0).cpu()
+        b = ctx.sample_loop(noise=None, seed=5, clip_id_base=0).cpu()
+        assert torch.equal(a, b)
+        ref = O.sample_loop(sd, arch, tab, cond, (B, 99, 1, T),
+                            lambda k: torch.from_numpy(O.philox_normal(5, np.arange(B), k, 99, T)))
+        assert float((a - ref).abs().max()) < 1e-3
+        outs.setdefault((B, T), []).append(a)
+        g = torch.Generator().manual_seed(1)
+        draws = torch.randn(7, B, 99, 1, T, generator=g)
+        c = ctx.sample_loop(noise=draws).cpu()
+        refc = O.sample_loop(sd, arch, tab, cond, (B, 99, 1, T), lambda k: draws[k])
+        assert float((c - refc).abs().max()) < 1e-3
+    assert torch.equal(outs[(4, 32)][0], outs[(4, 32)][1])
+    ctx.close()
+
+
+def test_two_contexts_do_not_interfere():
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd1, sd2 = O.det_state_dict(arch, tag="two/a"), O.det_state_dict(arch, tag="two/b")
+    c1, c2 = _ctx(arch, sd1, 2, 16), _ctx(arch, sd2, 2, 16)
+    cond = _cond(2, 16, "two/c")
+    _set_cond(c1, cond)
+    _set_cond(c2, cond)
+    x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([4, 900])
+    o1a = c1.denoise(x, t).cpu()
+    o2 = c2.denoise(x, t).cpu()
+    o1b = c1.denoise(x, t).cpu()
+    assert torch.equal(o1a, o1b) and not torch.equal(o1a, o2)
+    assert float((o1a - O.denoiser_forward(sd1, arch, x, t, cond)).abs().max()) < 2e-5
+    assert float((o2 - O.denoiser_forward(sd2, arch, x, t, cond)).abs().max()) < 2e-5
+    c1.close()
+    c2.close()
+
+
+def test_ddpm_step_entry_point():
+    """tamf_ddpm_step reproduces the oracle's float32 arithmetic (same op order, no FMA contraction); the only source of
+    difference is the last bit of sigma = exp(0.5 * logvar) (libm expf vs torch.exp), hence 1e-6 instead of bit equality;
+    t = 0 (no noise term) is exact."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY
+    ctx = _ctx(arch, O.det_state_dict(arch, tag="rob/w"), 2, 16, n_steps=1000)
+    tab = O.make_tables(1000, "cosine")
+    g = torch.Generator().manual_seed(9)
+    xt, x0, nz = (torch.randn(2, 99, 1, 16, generator=g) for _ in range(3))
+    for t in (0, 1, 500, 999):
+        got = ctx.ddpm_step(xt, x0, t, nz).cpu()
+        ref = O.ddpm_step(tab, xt, x0, t, nz)
+        if t == 0:
+            assert torch.equal(got, ref)
+        assert float((got - ref).abs().max()) < 1e-6, t
+    ctx.close()
