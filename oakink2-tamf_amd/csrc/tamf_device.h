@@ -22,6 +22,8 @@ TAMF_DEV float nan_to_num(float v) {
   return v;
 }
 TAMF_DEV float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 form (each ~1 ulp) for the bf16 modes
+TAMF_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 TAMF_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7 + exp/rcp rounding): ~3x fewer VALU instructions than the
 // libm erff; used by the bf16 / bf16x3 epilogues (the f32 parity mode keeps erff)
@@ -209,15 +211,20 @@ TAMF_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// element e of clip `clip` at draw `draw`: counter (e >> 2, draw, clip_lo, clip_hi), key (seed_lo, seed_hi)
-TAMF_DEV float philox_normal_elem(uint64_t seed, int64_t clip, uint32_t draw, uint32_t e) {
+// The four normals of Philox block `blk` of clip `clip` at draw `draw`: counter (blk, draw, clip_lo, clip_hi), key
+// (seed_lo, seed_hi); outputs (0,1) and (2,3) are two Box-Muller pairs.  Element e of the sampler state (frame-major,
+// 128-padded: e = tau*128 + feature) is component e & 3 of block e >> 2.
+TAMF_DEV void philox_normal4(uint64_t seed, int64_t clip, uint32_t draw, uint32_t blk, float (&z)[4]) {
   uint32_t r[4];
-  philox4x32_10(e >> 2, draw, (uint32_t)((uint64_t)clip & 0xFFFFFFFFu), (uint32_t)((uint64_t)clip >> 32),
+  philox4x32_10(blk, draw, (uint32_t)((uint64_t)clip & 0xFFFFFFFFu), (uint32_t)((uint64_t)clip >> 32),
                 (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), r);
-  const int pair = (e >> 1) & 1;
-  const float u0 = __fadd_rn(__fmul_rn((float)r[2 * pair], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
-  const float u1 = __fadd_rn(__fmul_rn((float)r[2 * pair + 1], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
-  const float rad = sqrtf(__fmul_rn(-2.0f, logf(u0)));
-  const float ang = __fmul_rn(6.283185307179586f, u1);
-  return (e & 1) ? __fmul_rn(rad, sinf(ang)) : __fmul_rn(rad, cosf(ang));
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {
+    const float u0 = __fadd_rn(__fmul_rn((float)r[2 * pair], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
+    const float u1 = __fadd_rn(__fmul_rn((float)r[2 * pair + 1], 2.3283064365386963e-10f), 1.1641532182693481e-10f);
+    const float rad = sqrtf(__fmul_rn(-2.0f, logf(u0)));
+    const float ang = __fmul_rn(6.283185307179586f, u1);
+    z[2 * pair] = __fmul_rn(rad, cosf(ang));
+    z[2 * pair + 1] = __fmul_rn(rad, sinf(ang));
+  }
 }

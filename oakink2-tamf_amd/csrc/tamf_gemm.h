@@ -92,8 +92,13 @@ struct EpiBiasAct {
         for (int j = 0; j < 8; ++j) v[j] += b[j];
       }
       if (act == ACT_SILU) {
+        if constexpr (OutOp::PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
+          for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = silu_fast(v[j]);
+        }
       } else if (act == ACT_GELU || act == 102) {
         if constexpr (OutOp::PREC == 0) {
 #pragma unroll
@@ -303,8 +308,25 @@ struct EpiHead {
         const float k1 = c1[ti], k2 = c2[ti], sg = sigma[ti];
         const unsigned draw = (unsigned)(n_steps - ti);
         const long srow = ((long)b * T + tau) * XK;
-        float xt[8], xn[8];
+        float xt[8], xn[8], ez[8];
         g_load8(xs + srow + gn, xt);
+        if (ti != 0) {
+          if (noise) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              ez[j] = (gn + j < F) ? noise[(long)draw * noise_draw_stride + ((long)b * F + gn + j) * T + tau] : 0.f;
+          } else {  // 8 consecutive features of one frame = 2 Philox blocks
+            float z0[4], z1[4];
+            const unsigned blk = ((unsigned)tau * 128u + (unsigned)gn) >> 2;
+            philox_normal4(seed, clip_base + b, draw, blk, z0);
+            philox_normal4(seed, clip_base + b, draw, blk + 1, z1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ez[j] = z0[j];
+              ez[4 + j] = z1[j];
+            }
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
@@ -312,12 +334,7 @@ struct EpiHead {
             const float x0 = nan_to_num(v[j] + bi[j]);
             // mean = coef1*x0 + coef2*x_t ; sample = mean + [t!=0]*sigma*eps  (gaussian_diffusion.py:221-224,459)
             float r = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xt[j]));
-            if (ti != 0) {
-              float e;
-              if (noise) e = noise[(long)draw * noise_draw_stride + ((long)b * F + c) * T + tau];
-              else e = philox_normal_elem(seed, clip_base + b, draw, (unsigned)(c * T + tau));
-              r = __fadd_rn(r, __fmul_rn(sg, e));
-            }
+            if (ti != 0) r = __fadd_rn(r, __fmul_rn(sg, ez[j]));
             xn[j] = r;
             if (dump) dump[(long)(draw - 1) * noise_draw_stride + ((long)b * F + c) * T + tau] = r;
           } else {

@@ -238,7 +238,7 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
@@ -716,8 +716,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
   }
   {
+    // N = 128 is a single column tile: 64-row tiles (8 waves) double the workgroups that share the Philox-heavy epilogue
     GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)ctx->Wf.p, d, M, ctx->XN, d, 0};
-    HIPCHK(ctx, gemm128<Op>(ga, head_in, st));
+    HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head_in, st)));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
   ctx->step_kernels = nk;

@@ -14,15 +14,22 @@ __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__
   const int cg = idx % CG, bt = idx / CG;
   const int b = bt / T, tau = bt % T;
   float v[8];
+  if (philox) {  // draw 0: 8 consecutive features of one frame = 2 Philox blocks
+    float z0[4], z1[4];
+    const unsigned blk = ((unsigned)tau * 128u + (unsigned)(cg * 8)) >> 2;
+    philox_normal4(seed, clip_base + b, 0u, blk, z0);
+    philox_normal4(seed, clip_base + b, 0u, blk + 1, z1);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = cg * 8 + j;
-    float val = 0.f;
-    if (c < F) {
-      if (philox) val = philox_normal_elem(seed, clip_base + b, 0u, (unsigned)(c * T + tau));
-      else val = x[((long)b * F + c) * T + tau];
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (cg * 8 + j < F) ? z0[j] : 0.f;
+      v[4 + j] = (cg * 8 + 4 + j < F) ? z1[j] : 0.f;
     }
-    v[j] = val;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      v[j] = c < F ? x[((long)b * F + c) * T + tau] : 0.f;
+    }
   }
   float* p = xs + (long)bt * XK + cg * 8;
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
@@ -238,5 +245,9 @@ __global__ void philox_fill_kernel(float* out, unsigned long long seed, long lon
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * F * T) return;
   const int e = idx % (F * T), b = idx / (F * T);
-  out[idx] = philox_normal_elem(seed, clip_base + b, draw, (unsigned)e);
+  const int f = e / T, tau = e % T;  // out is (B, F, 1, T); the stream is keyed frame-major (tau*128 + f)
+  float z[4];
+  const unsigned el = (unsigned)tau * 128u + (unsigned)f;
+  philox_normal4(seed, clip_base + b, draw, el >> 2, z);
+  out[idx] = z[el & 3];
 }

@@ -449,11 +449,13 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_normal(seed: int, clip_ids: np.ndarray, draw_index: int, n_feat: int, T: int) -> np.ndarray:
     """Noise tensor (len(clip_ids), n_feat, 1, T) float32 exactly as the HIP library generates it:
-    element e = f*T + tau of clip c at draw k uses counter (e >> 2, k, c_lo, c_hi), key (seed_lo, seed_hi);
-    the four 32-bit outputs give two Box-Muller pairs; element e takes output (e & 3)."""
+    element e = tau*128 + f (the frame-major, 128-padded order of the sampler state) of clip c at draw k uses counter
+    (e >> 2, k, c_lo, c_hi), key (seed_lo, seed_hi); the four 32-bit outputs give two Box-Muller pairs; element e
+    takes output (e & 3)."""
     n = n_feat * T
     out = np.empty((len(clip_ids), n), dtype=np.float32)
-    e = np.arange(n, dtype=np.uint64)
+    ff, tt = np.meshgrid(np.arange(n_feat, dtype=np.uint64), np.arange(T, dtype=np.uint64), indexing="ij")
+    e = (tt * np.uint64(128) + ff).reshape(-1)
     grp = (e >> np.uint64(2)).astype(np.uint32)
     lane = (e & np.uint64(3)).astype(np.int64)
     for r, c in enumerate(clip_ids):

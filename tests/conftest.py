@@ -12,6 +12,7 @@ for p in (ROOT, PKG_PARENT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+collect_ignore = ["scripts"]  # measurement / report scripts that use the oracle as checker, not tests
 
 
 def pytest_configure(config):
