@@ -72,19 +72,20 @@ struct EpiBiasAct {
   int act;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    constexpr int VPR = BN / 8;
-    for (int it = tid; it < BM * VPR; it += NT) {
-      const int row = it / VPR, col = (it % VPR) * 8;
-      const int gr = m0 + row, gn = n0 + col;
-      if (gr >= M) continue;
+    // NT is a multiple of the BN/8 column groups: a thread keeps its 8 columns for all its rows, so the bias vector is
+    // loaded once (a global load inside the row loop serialises the loop on L2 latency)
+    constexpr int VPR = BN / 8, RSTEP = NT / VPR;
+    static_assert(NT % VPR == 0, "column group must be fixed per thread");
+    const int col = (tid % VPR) * 8, gn = n0 + col;
+    float bi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias) g_load8(bias + gn, bi);
+    for (int row = tid / VPR; row < BM; row += RSTEP) {
+      const int gr = m0 + row;
+      if (gr >= M) break;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
-      if (bias) {
-        float b[8];
-        g_load8(bias + gn, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
-      }
+      for (int j = 0; j < 8; ++j) v[j] += bi[j];
       if (rowadd) {
         float b[8];
         g_load8(rowadd + (long)gr * ld_rowadd + gn, b);
@@ -99,7 +100,7 @@ struct EpiBiasAct {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = silu_fast(v[j]);
         }
-      } else if (act == ACT_GELU || act == 102) {
+      } else if (act == ACT_GELU) {
         if constexpr (OutOp::PREC == 0) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
@@ -108,7 +109,7 @@ struct EpiBiasAct {
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
         }
       }
-      if (act < 100 || v[0] == 1.2345e-30f) OutOp::template store<8>(out, (long)gr * ldo + gn, v);  // act >= 100: bench ablation "no stores"
+      OutOp::template store<8>(out, (long)gr * ldo + gn, v);
     }
   }
 };
@@ -125,15 +126,17 @@ struct EpiQKV {
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     if (n0 < 2 * d) {
-      constexpr int VPR = BN / 8;
+      constexpr int VPR = BN / 8, RSTEP = NT / VPR;
+      static_assert(NT % VPR == 0, "column group must be fixed per thread");
       const float sc = (n0 < d) ? qscale : 1.0f;
-      for (int it = tid; it < BM * VPR; it += NT) {
-        const int row = it / VPR, col = (it % VPR) * 8;
-        const int gr = m0 + row, gn = n0 + col;
-        if (gr >= M) continue;
-        float v[8], b[8];
+      const int col = (tid % VPR) * 8, gn = n0 + col;
+      float b[8];
+      g_load8(bias + gn, b);
+      for (int row = tid / VPR; row < BM; row += RSTEP) {
+        const int gr = m0 + row;
+        if (gr >= M) break;
+        float v[8];
         ct_load8(Ct, LDC, row, col, v);
-        g_load8(bias + gn, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
         Op::template store<8>(qk, (long)gr * (2 * d) + gn, v);
@@ -175,16 +178,18 @@ struct EpiSeqRows {
   int d, Tdiv, Sp, P;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    constexpr int VPR = BN / 8;
-    for (int it = tid; it < BM * VPR; it += NT) {
-      const int row = it / VPR, col = (it % VPR) * 8;
-      const int gr = m0 + row, gn = n0 + col;
-      if (gr >= M) continue;
+    constexpr int VPR = BN / 8, RSTEP = NT / VPR;
+    static_assert(NT % VPR == 0, "column group must be fixed per thread");
+    const int col = (tid % VPR) * 8, gn = n0 + col;
+    float bi[8];
+    g_load8(bias + gn, bi);
+    for (int row = tid / VPR; row < BM; row += RSTEP) {
+      const int gr = m0 + row;
+      if (gr >= M) break;
       const int b = gr / Tdiv, tau = gr % Tdiv;
       const long orow = (long)b * Sp + P + tau;
-      float v[8], bi[8], pv[8];
+      float v[8], pv[8];
       ct_load8(Ct, LDC, row, col, v);
-      g_load8(bias + gn, bi);
       g_load8(pe + (long)tau * pe_stride + gn, pv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
@@ -279,17 +284,19 @@ struct EpiHead {
   float* dump;          // (n_steps, B, F, 1, T) or null
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    constexpr int VPR = BN / 8;
-    for (int it = tid; it < BM * VPR; it += NT) {
-      const int row = it / VPR, col = (it % VPR) * 8;
-      const int gr = m0 + row, gn = n0 + col;
-      if (gr >= M) continue;
+    constexpr int VPR = BN / 8, RSTEP = NT / VPR;
+    static_assert(NT % VPR == 0, "column group must be fixed per thread");
+    const int col = (tid % VPR) * 8, gn = n0 + col;
+    float bi[8];
+    g_load8(bias + gn, bi);
+    for (int row = tid / VPR; row < BM; row += RSTEP) {
+      const int gr = m0 + row;
+      if (gr >= M) break;
       const int b = gr / Sp, s = gr % Sp;
       if (s < P || s >= P + T) continue;
       const int tau = s - P;
-      float v[8], bi[8];
+      float v[8];
       ct_load8(Ct, LDC, row, col, v);
-      g_load8(bias + gn, bi);
       if (mode == HEAD_X0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -356,19 +363,18 @@ struct EpiStoreF32 {
   int act;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    constexpr int VPR = BN / 8;
-    for (int it = tid; it < BM * VPR; it += NT) {
-      const int row = it / VPR, col = (it % VPR) * 8;
-      const int gr = m0 + row, gn = n0 + col;
-      if (gr >= M) continue;
+    constexpr int VPR = BN / 8, RSTEP = NT / VPR;
+    static_assert(NT % VPR == 0, "column group must be fixed per thread");
+    const int col = (tid % VPR) * 8, gn = n0 + col;
+    float bi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias) g_load8(bias + gn, bi);
+    for (int row = tid / VPR; row < BM; row += RSTEP) {
+      const int gr = m0 + row;
+      if (gr >= M) break;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
-      if (bias) {
-        float b[8];
-        g_load8(bias + gn, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
-      }
+      for (int j = 0; j < 8; ++j) v[j] += bi[j];
       if (act == ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
