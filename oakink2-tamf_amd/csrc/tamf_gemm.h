@@ -536,9 +536,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
       ktp = ktp >= KT ? ktp - KT : ktp;
       tv = __hip_atomic_load((const unsigned*)(tbase + (long)ktp * BKB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // next tile's pieces first: their latency is covered by this tile's MFMAs (waited for at the barrier below)
-    if (more) TAMF_ISSUE_ALL(ktn, cur ^ 1)
-    if (!abl_nocomp) {
+    {
       // all fragments of the tile are requested up front: LDS latency is paid once and the MFMAs stream behind
       // counted lgkmcnt waits
       int4 af[MI][2], wf[NI][2];
@@ -552,10 +550,16 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
         wf[ni][0] = *(const int4*)(cb + w_frag + ni * 16 * BKB + c0);
         wf[ni][1] = *(const int4*)(cb + w_frag + ni * 16 * BKB + c1);
       }
+      // the next tile's pieces are issued AFTER this tile's fragment reads: hipcc places a vmcnt(0) in front of any
+      // LDS read that follows an LDS-DMA in program order, which would serialise the DMA latency with the MFMAs;
+      // issued here the pieces fly under the MFMAs and are waited for at the barrier below
+      if (more) TAMF_ISSUE_ALL(ktn, cur ^ 1)
+      if (!abl_nocomp) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g+reg), cols = m (lr)
+          for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g+reg), cols = m (lr)
+      }
     }
     __syncthreads();
     tsink ^= tv;  // consumed after the barrier's vmcnt(0): keeps the touch load alive without an extra wait
