@@ -2,8 +2,8 @@
 // (clip, head); interaction_segment_mdm.py:63-70,171 -> nn.MultiheadAttention).
 //
 // Workgroup = NW waves = NW tiles of 16 queries of one (clip, head); keys/values are streamed through LDS in
-// blocks of 32 keys (LDS-DMA, double-buffered: block kb+1 is in flight while block kb is multiplied) with an
-// online softmax, so LDS and registers are bounded for every arithmetic mode.
+// blocks of 32 keys (LDS-DMA, double-buffered: block kb+1 is in flight while block kb is multiplied, see AttnBlock)
+// with an online softmax, so LDS and registers are bounded for every arithmetic mode.
 // Both products run "swapped" so that the softmax axis (keys) lies along the MFMA row index and each lane owns
 // one query column:
 //     S^T[key][query] = K . Q^T      A operand = K rows from LDS (swizzled, ds_read_b128), B operand = Q (registers)
@@ -39,82 +39,55 @@ struct AttnCfg {
   static_assert(KROWB % 128 == 0, "head slice must be whole 128-byte groups");
 };
 
+// One block of 32 keys for one wave: issue block kb+1 into `nxt`, then S^T, online softmax and O^T += V^T P^T on
+// the block in `cur`.  `cur` and `nxt` are the two LDS stages and never overlap; declaring them __restrict__ on this
+// (inlined) helper is what lets the LDS-DMA stay in flight: without the alias scopes hipcc puts an s_waitcnt vmcnt(0)
+// in front of the first LDS read that follows an LDS-DMA in program order, which serialises the next block's latency
+// with this block's math.  The landed data is published by the caller's vmcnt(0) + barrier.
 template <class Op, int HD>
-__global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
+struct AttnBlock {
   typedef AttnCfg<Op, HD> C;
-  constexpr int EB = Op::EB, KG = C::KG;
-  constexpr int NT16 = HD / 16;  // output tiles along e
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, nw = nthr >> 6;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / aa.H, h = bh % aa.H;
-  const int q0 = (blockIdx.x * nw + wave) * 16;
-  const bool active = q0 < aa.Sp;
-  const int S = aa.S, Sp = aa.Sp, d = aa.d;
-  const long row_base = (long)b * Sp;
-
-  // Q fragments (B operand): lane (g, lr) -> query q0+lr, fragments g and 4+g of each 128-byte group of its head slice
-  int4 qf[KG][2];
-  {
-    int q = q0 + lr;
-    q = q < Sp ? q : Sp - 1;
-    const char* qb = (const char*)aa.qk + ((row_base + q) * (2 * d) + h * HD) * EB + g * 16;
-#pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-      qf[kg][0] = *(const int4*)(qb + kg * 128);
-      qf[kg][1] = *(const int4*)(qb + kg * 128 + 64);
-    }
-  }
-
-  f32x4 o[NT16];
-#pragma unroll
-  for (int nt = 0; nt < NT16; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int nkb = (S + 31) / 32;
-  constexpr int KCH = C::KROWB / 16;  // chunks per K row
-  constexpr int VCH = C::VROWB / 16;  // chunks per V^T row block
+  static constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16;
+  static constexpr int KCH = C::KROWB / 16;  // chunks per K row
+  static constexpr int VCH = C::VROWB / 16;  // chunks per V^T row block
   // chunk swizzles (involutions): K rows of 128 bytes use the GEMM tile swizzle, longer K rows XOR the low 4 chunk
   // bits with the row; V^T rows see the comment at AttnCfg::VSTR
-  auto kswz = [](int ch, int row) -> int {
+  static TAMF_DEV int kswz(int ch, int row) {
     if constexpr (C::KROWB >= 256) return (ch & ~15) | ((ch ^ row) & 15);
     else return ch ^ ((row >> 1) & 7);
-  };
-  auto vswz = [](int ch, int e) -> int {
+  }
+  static TAMF_DEV int vswz(int ch, int e) {
     if constexpr (C::VROWB == 128) return ch ^ ((e >> 1) & 7);
     else return ch ^ swz_chunk<64>(e);
-  };
+  }
   // LDS-DMA pieces (1 KiB = 64 lanes x 16 B, linear in LDS; the swizzle goes on each lane's SOURCE chunk)
-  constexpr int K_RPP = 1024 / C::KROWB, K_PIECES = C::K_BYTES / 1024;  // K rows per piece
-  constexpr int V_RPP = 1024 / C::VROWB, V_PIECES = C::V_BYTES / 1024;
-  const char* kbase = (const char*)aa.qk + (row_base * (2 * d) + d + h * HD) * EB;
-  const char* vbase = (const char*)aa.vt + ((long)bh * HD) * aa.Skp * EB;
-  auto issue_block = [&](int kb, int stage) {
-    char* st = smem + stage * C::STAGE;
+  static constexpr int K_RPP = 1024 / C::KROWB, K_PIECES = C::K_BYTES / 1024;  // K rows per piece
+  static constexpr int V_RPP = 1024 / C::VROWB, V_PIECES = C::V_BYTES / 1024;
+
+  static TAMF_DEV void issue(char* __restrict__ st, const char* kbase, const char* vbase, int kb, int Sp, int d, int Skp,
+                             int wave, int nw, int lane) {
     for (int q = wave; q < K_PIECES; q += nw) {
       const int r = q * K_RPP + lane / KCH, pc = lane % KCH;
       int key = kb * 32 + r;
-      key = key < Sp ? key : Sp - 1;  // rows past the clip are clamped; they are masked below
+      key = key < Sp ? key : Sp - 1;  // rows past the clip are clamped; they are masked in run()
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)key * (2 * d) * EB + kswz(pc, r) * 16),
                                        (__attribute__((address_space(3))) void*)(st + q * 1024), 16, 0, 0);
     }
     for (int q = wave; q < V_PIECES; q += nw) {
       const int e = q * V_RPP + lane / VCH, pc = lane % VCH;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long)e * aa.Skp + kb * 32) * EB + vswz(pc, e) * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long)e * Skp + kb * 32) * EB + vswz(pc, e) * 16),
                                        (__attribute__((address_space(3))) void*)(st + C::K_BYTES + q * 1024), 16, 0, 0);
     }
-  };
+  }
 
-  issue_block(0, 0);
-  __syncthreads();
-  for (int kb = 0; kb < nkb; ++kb) {
-    const char* Ks = smem + (kb & 1) * C::STAGE;
-    const char* Vs = Ks + C::K_BYTES;
-    if (kb + 1 < nkb) issue_block(kb + 1, (kb + 1) & 1);
-    if (active) {
+  static TAMF_DEV void run(const char* __restrict__ cur, char* __restrict__ nxt, const char* kbase, const char* vbase,
+                           int kb, int nkb, int S, int Sp, int d, int Skp, int wave, int nw, int lane, bool active,
+                           const int4 (&qf)[KG][2], f32x4 (&o)[NT16], float& m_run, float& l_run) {
+    const int lr = lane & 15, g = lane >> 4;
+    const char* Ks = cur;
+    const char* Vs = cur + C::K_BYTES;
+    if (kb + 1 < nkb) issue(nxt, kbase, vbase, kb + 1, Sp, d, Skp, wave, nw, lane);
+    if (!active) return;
 
     // ---- S^T tiles: keys 16t + 4g + reg, query lr
     f32x4 st[2];
@@ -208,9 +181,73 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
         o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[nt], 0, 0, 0);
       }
     }
-    }  // active
+  }
+};
+
+#ifdef TAMF_TIMELINE  // debug build: per-workgroup wall-clock stamps (tools/attn_timeline.py)
+__device__ unsigned long long g_attn_ts[8192 * 4];
+#endif
+
+template <class Op, int HD>
+__global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
+  TAMF_TS(ts0);
+  typedef AttnCfg<Op, HD> C;
+  typedef AttnBlock<Op, HD> BLK;
+  constexpr int EB = Op::EB, KG = C::KG;
+  constexpr int NT16 = HD / 16;  // output tiles along e
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, nw = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / aa.H, h = bh % aa.H;
+  const int q0 = (blockIdx.x * nw + wave) * 16;
+  const bool active = q0 < aa.Sp;
+  const int S = aa.S, Sp = aa.Sp, d = aa.d;
+  const long row_base = (long)b * Sp;
+
+  // Q fragments (B operand): lane (g, lr) -> query q0+lr, fragments g and 4+g of each 128-byte group of its head slice
+  int4 qf[KG][2];
+  {
+    int q = q0 + lr;
+    q = q < Sp ? q : Sp - 1;
+    const char* qb = (const char*)aa.qk + ((row_base + q) * (2 * d) + h * HD) * EB + g * 16;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      qf[kg][0] = *(const int4*)(qb + kg * 128);
+      qf[kg][1] = *(const int4*)(qb + kg * 128 + 64);
+    }
+  }
+
+  f32x4 o[NT16];
+#pragma unroll
+  for (int nt = 0; nt < NT16; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nkb = (S + 31) / 32;
+  const char* kbase = (const char*)aa.qk + (row_base * (2 * d) + d + h * HD) * EB;
+  const char* vbase = (const char*)aa.vt + ((long)bh * HD) * aa.Skp * EB;
+
+  BLK::issue(smem, kbase, vbase, 0, Sp, d, aa.Skp, wave, nw, lane);
+  __syncthreads();
+  TAMF_TS(ts1);
+  for (int kb = 0; kb < nkb; ++kb) {
+    BLK::run(smem + (kb & 1) * C::STAGE, smem + ((kb + 1) & 1) * C::STAGE, kbase, vbase, kb, nkb, S, Sp, d, aa.Skp, wave, nw,
+             lane, active, qf, o, m_run, l_run);
     __syncthreads();  // block kb+1 has landed (vmcnt(0) + barrier) and everyone is done reading block kb
   }
+#ifdef TAMF_TIMELINE
+  if (tid == 0) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 8192) {
+      g_attn_ts[wg * 4 + 0] = ts0;
+      g_attn_ts[wg * 4 + 1] = ts1;
+      g_attn_ts[wg * 4 + 2] = wall_clock64();
+      g_attn_ts[wg * 4 + 3] = tamf_hw_cu_id();
+    }
+  }
+#endif
 
   if (!active) return;
   const int q = q0 + lr;

@@ -9,6 +9,18 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define TAMF_DEV __device__ __forceinline__
 
+// -DTAMF_TIMELINE: debug build whose GEMM and attention kernels stamp per-workgroup phase times (100 MHz wall clock)
+// into device buffers read back by tamf_debug_timeline (tools/gemm_timeline.py, tools/attn_timeline.py)
+#ifdef TAMF_TIMELINE
+#define TAMF_TS(var) const unsigned long long var = wall_clock64()
+__device__ __forceinline__ unsigned long long tamf_hw_cu_id() {  // (XCC id << 32) | HW_ID (cu, sh, se in bits 8..15)
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  return ((unsigned long long)(xcc & 15) << 32) | hw;
+}
+#else
+#define TAMF_TS(var)
+#endif
+
 TAMF_DEV uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
 TAMF_DEV float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
 TAMF_DEV float as_f(int v) { return __builtin_bit_cast(float, v); }

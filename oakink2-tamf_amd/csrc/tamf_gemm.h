@@ -420,9 +420,13 @@ struct GemmOcc {
   static constexpr int WAVES_PER_SIMD = (WG_PER_CU * NWV / 4) > 0 ? (WG_PER_CU * NWV / 4) : 1;
 };
 
+#ifdef TAMF_TIMELINE
+__device__ unsigned long long g_gemm_ts[8192 * 5];
+#endif
 template <class Op, int BM, int BN, int WGM, int WGN, class Epi>
 __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel(
     const GemmArgs<Op> ga, const Epi epi) {
+  TAMF_TS(ts0);
   constexpr int BKB = GEMM_BKB;
   constexpr int NT = WGM * WGN * 64;
   constexpr int NWV = WGM * WGN;
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   const int rot = krs ? (int)(((unsigned)lb * (unsigned)krs) % (unsigned)KT) : 0;
   TAMF_ISSUE_ALL(rot, 0)
   __syncthreads();
+  TAMF_TS(ts1);
 
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
@@ -566,6 +571,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   }
 #undef TAMF_ISSUE_ALL
 
+  TAMF_TS(ts2);
   // park the accumulators in the LDS C tile: lane (g, lr) holds C[m = lr][n = 4g .. 4g+3] of each 16x16 tile
   float* Ct = (float*)smem;
 #pragma unroll
@@ -578,4 +584,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   __syncthreads();
   if (tsink == 0x9E3779B9u && ga.M < 0) Ct[0] = 1.0f;  // never true; keeps the touch loads from being optimised away
   epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
+#ifdef TAMF_TIMELINE
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned long long* o = g_gemm_ts + blockIdx.x * 5;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = wall_clock64(); o[4] = tamf_hw_cu_id();
+  }
+#endif
 }

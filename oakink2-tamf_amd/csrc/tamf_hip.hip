@@ -1156,3 +1156,11 @@ extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t dra
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
   return 0;
 }
+
+#ifdef TAMF_TIMELINE
+// debug builds only (not part of include/tamf_hip.h): which = 0 GEMM (5 u64 per workgroup), 1 attention (4 u64)
+extern "C" int tamf_debug_timeline(int which, void* dst, size_t bytes) {
+  if (which == 0) return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_ts), bytes, 0, hipMemcpyDeviceToHost);
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_ts), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
