@@ -125,7 +125,7 @@ int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64
 int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
                 void* stream);
 
-/* ---- geometry either side of the trunks (SURVEY.md section 8f rows 1, 2) ---------------------------- */
+/* ---- geometry either side of the trunks (SURVEY.md section 8f rows 1, 2, 4) ---------------------------- */
 /* Pose decode of launch/sample_refine.py:254-260 / model/segment_refine_model.py:117-124:
  * pose_repr (n_frames, 3 + 6*n_joints) f32 -> tsl (n_frames, 3) [may be NULL] and unit quaternions
  * (n_frames, n_joints, 4) in (w, x, y, z) order with w >= 0 (dev_fn/transform/rotation.py:446-467,167-213,24-35). */
@@ -139,6 +139,13 @@ int tamf_pose_decode(const float* pose_repr_dev, int64_t n_frames, int32_t n_joi
 int tamf_h2o_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
                   const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
                   float* h2o_out_dev, void* stream);
+/* Per-frame contact distance of the Contact-Ratio score (script/compute_score/compute_score_cr.py:122-149,282-283:
+ * transf_merge_obj_pointcloud + torch.cdist(hand_verts, merged_points).min per frame; a frame is "in contact" when
+ * the value is < 0.005 m):  min_dist[b,t] = min_v h2o[b,t,v] with h2o as in tamf_h2o_dist.  Same argument layout;
+ * min_dist_out (B,T). */
+int tamf_contact_min_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                          const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
+                          float* min_dist_out_dev, void* stream);
 
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);

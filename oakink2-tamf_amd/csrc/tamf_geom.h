@@ -63,11 +63,15 @@ __global__ void pose_decode_kernel(const float* __restrict__ pose, float* __rest
 // (oakink2_tamf/model/segment_refine_model.py:142-168, model/loss/chamfer_distance.py:4-64 with y_normals = None).
 // One workgroup per (t, b): every thread keeps up to 4 hand vertices in registers; object points are transformed to
 // the frame's pose on the fly and streamed through LDS in tiles of 256, read back as 16-byte broadcasts.
+// frame_min[b, t] (optional) = min over v of h2o[b, t, v]: the per-frame contact distance of the Contact-Ratio score
+// (script/compute_score/compute_score_cr.py:122-149: transf_merge_obj_pointcloud + torch.cdist(...).min per frame).
 constexpr int H2O_VPT = 4;
 __global__ __launch_bounds__(256) void h2o_dist_kernel(const float* __restrict__ hand, const float* __restrict__ traj,
                                                        const float* __restrict__ pts, const int* __restrict__ obj_num,
-                                                       float* __restrict__ out, int T, int V, int nobj, int P) {
+                                                       float* __restrict__ out, float* __restrict__ frame_min, int T,
+                                                       int V, int nobj, int P) {
   __shared__ float4 tile[256];
+  __shared__ float wmin[4];
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* hv = hand + ((long)b * T + t) * V * 3;
   float vx[H2O_VPT], vy[H2O_VPT], vz[H2O_VPT], best[H2O_VPT];
@@ -112,9 +116,21 @@ __global__ __launch_bounds__(256) void h2o_dist_kernel(const float* __restrict__
       }
     }
   }
+  float fm = 3.0e38f;
 #pragma unroll
   for (int i = 0; i < H2O_VPT; ++i) {
     const int v = tid + 256 * i;
-    if (v < V) out[((long)b * T + t) * V + v] = sqrtf(best[i]);
+    if (v < V) {
+      const float dv = sqrtf(best[i]);
+      if (out) out[((long)b * T + t) * V + v] = dv;
+      fm = fminf(fm, dv);
+    }
+  }
+  if (frame_min) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fm = fminf(fm, __shfl_xor(fm, off, 64));
+    if ((tid & 63) == 0) wmin[tid >> 6] = fm;
+    __syncthreads();
+    if (tid == 0) frame_min[(long)b * T + t] = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
   }
 }

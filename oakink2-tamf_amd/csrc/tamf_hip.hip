@@ -1128,18 +1128,33 @@ extern "C" int tamf_pose_decode(const float* pose_repr_dev, int64_t n_frames, in
   return 0;
 }
 
-extern "C" int tamf_h2o_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
-                             const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
-                             float* h2o_out_dev, void* stream) {
-  if (!hand_verts_dev || !obj_traj_dev || !obj_points_dev || !h2o_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+static int h2o_launch(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                      const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P, float* h2o_out_dev,
+                      float* frame_min_dev, void* stream) {
+  if (!hand_verts_dev || !obj_traj_dev || !obj_points_dev || (!h2o_out_dev && !frame_min_dev))
+    return fail(nullptr, TAMF_ERR_INVALID, "null argument");
   if (B <= 0 || T <= 0 || V <= 0 || nobj <= 0 || P <= 0) return fail(nullptr, TAMF_ERR_INVALID, "bad shape");
   if (V > 256 * H2O_VPT) return fail(nullptr, TAMF_ERR_INVALID, "at most 1024 hand vertices per frame (MANO has 778)");
   if (B > 65535) return fail(nullptr, TAMF_ERR_INVALID, "batch too large for one launch");
   hipLaunchKernelGGL(h2o_dist_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, hand_verts_dev, obj_traj_dev,
-                     obj_points_dev, (const int*)obj_num_dev, h2o_out_dev, T, V, nobj, P);
+                     obj_points_dev, (const int*)obj_num_dev, h2o_out_dev, frame_min_dev, T, V, nobj, P);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
   return 0;
+}
+
+extern "C" int tamf_h2o_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                             const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
+                             float* h2o_out_dev, void* stream) {
+  if (!h2o_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  return h2o_launch(hand_verts_dev, obj_traj_dev, obj_points_dev, obj_num_dev, B, T, V, nobj, P, h2o_out_dev, nullptr, stream);
+}
+
+extern "C" int tamf_contact_min_dist(const float* hand_verts_dev, const float* obj_traj_dev, const float* obj_points_dev,
+                                     const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
+                                     float* min_dist_out_dev, void* stream) {
+  if (!min_dist_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  return h2o_launch(hand_verts_dev, obj_traj_dev, obj_points_dev, obj_num_dev, B, T, V, nobj, P, nullptr, min_dist_out_dev, stream);
 }
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {

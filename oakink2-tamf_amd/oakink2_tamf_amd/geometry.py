@@ -4,7 +4,9 @@ pose_repr_to_quat      reference: rot6d_to_rotmat + rotmat_to_quat (dev_fn/trans
                        launch/sample_refine.py:254-260 and model/segment_refine_model.py:117-124 before the MANO layer
 multi_object_h2o_dist  reference: SegmentRefineModel.multi_object_h2o_dist (model/segment_refine_model.py:142-168) ->
                        point2point_signed (model/loss/chamfer_distance.py:4-64) -> external chamfer_distance CUDA extension
-Both return torch tensors on the inputs' device; no CPU fallback."""
+contact_min_dist       reference: transf_merge_obj_pointcloud + contact_min_cdist (script/compute_score/compute_score_cr.py:122-149),
+contact_ratio          the Contact-Ratio score built on it (:282-283, threshold 5 mm)
+All return torch tensors on the inputs' device; no CPU fallback."""
 from __future__ import annotations
 
 from ctypes import c_void_p
@@ -21,6 +23,7 @@ def _bind():
     L = lib()
     L.tamf_pose_decode.argtypes = [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
     L.tamf_h2o_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
+    L.tamf_contact_min_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
     return L
 
 
@@ -40,9 +43,7 @@ def pose_repr_to_quat(pose_repr: torch.Tensor):
     return tsl, quat
 
 
-def multi_object_h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor,
-                          obj_num: Optional[Sequence[int]] = None) -> torch.Tensor:
-    """hand_verts (B,T,V,3), obj_traj (B,nobj,T,9), obj_points (B,nobj,P,3), obj_num per clip -> (B,T,V)."""
+def _h2o_call(entry: str, hand_verts, obj_traj, obj_points, obj_num, per_vertex: bool) -> torch.Tensor:
     dev = require_gpu(hand_verts.device)
     hv, tr, pts = _dev_f32(hand_verts, dev), _dev_f32(obj_traj, dev), _dev_f32(obj_points, dev)
     B, T, V, _ = hv.shape
@@ -52,9 +53,30 @@ def multi_object_h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_
     if obj_num is not None:
         on = torch.as_tensor(list(obj_num), dtype=torch.int32, device=dev)
         assert on.numel() == B
-    out = torch.empty((B, T, V), device=dev, dtype=torch.float32)
+    out = torch.empty((B, T, V) if per_vertex else (B, T), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        _check(_bind().tamf_h2o_dist(c_void_p(hv.data_ptr()), c_void_p(tr.data_ptr()), c_void_p(pts.data_ptr()),
-                                     c_void_p(on.data_ptr() if on is not None else 0), B, T, V, nobj, P,
-                                     c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+        _check(getattr(_bind(), entry)(c_void_p(hv.data_ptr()), c_void_p(tr.data_ptr()), c_void_p(pts.data_ptr()),
+                                       c_void_p(on.data_ptr() if on is not None else 0), B, T, V, nobj, P,
+                                       c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
     return out
+
+
+def multi_object_h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor,
+                          obj_num: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """hand_verts (B,T,V,3), obj_traj (B,nobj,T,9), obj_points (B,nobj,P,3), obj_num per clip -> (B,T,V)."""
+    return _h2o_call("tamf_h2o_dist", hand_verts, obj_traj, obj_points, obj_num, True)
+
+
+def contact_min_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor,
+                     obj_num: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Per-frame hand-object contact distance, (B,T): min over hand vertices and (transformed) object points."""
+    return _h2o_call("tamf_contact_min_dist", hand_verts, obj_traj, obj_points, obj_num, False)
+
+
+def contact_ratio(min_dist: torch.Tensor, valid_len: Optional[Sequence[int]] = None, threshold: float = 0.005) -> float:
+    """Fraction of frames in contact (compute_score_cr.py:282-283); valid_len[b] frames of clip b count (`avai_len`)."""
+    d = min_dist
+    if valid_len is not None:
+        keep = torch.arange(d.shape[1], device=d.device)[None, :] < torch.as_tensor(list(valid_len), device=d.device)[:, None]
+        d = d[keep]
+    return float((d < threshold).double().mean())

@@ -319,12 +319,48 @@ def capture_geometry():
                         h2o=ref.numpy())
 
 
+def capture_contact():
+    """Row 8(f)-4 (Contact Ratio): script/compute_score/compute_score_cr.py cannot be imported (config_reg, the dataset
+    toolkit and manotorch are absent), so its two functions are replayed call by call on the reference's own library:
+    transf_merge_obj_pointcloud (:122-137) = tslrot6d_to_transf_np + transf_point_array_np (dev_fn/transform/transform_np)
+    and contact_min_cdist (:140-149) = torch.cdist(hv, pc, p=2) -> min over (vertex, point) per frame."""
+    from dev_fn.transform.transform_np import tslrot6d_to_transf_np, transf_point_array_np
+    from . import geometry_oracle as G
+
+    B, T, V, nobj, P = 3, 12, 778, 2, 700
+    hv = det.det_normal("contact/hv", (B, T, V, 3)).astype(np.float32) * 0.08
+    traj = det.det_normal("contact/traj", (B, nobj, T, 9)).astype(np.float32)
+    traj[..., 0:3] *= 0.22  # object centres wander in and out of the hand's vertex cloud: a mix of contact / no contact
+    pts = det.det_normal("contact/pts", (B, nobj, P, 3)).astype(np.float32) * 0.02
+    # clip 2: object far away -> no contact in any frame
+    traj[2, :, :, 0:3] += 1.0
+    ref = np.zeros((B, T), np.float32)
+    for b in range(B):
+        obj_traj, obj_pointcloud = traj[b], pts[b]                                  # (nobj, T, 9), (nobj, P, 3)
+        transf = tslrot6d_to_transf_np(obj_traj)                                    # (nobj, T, 4, 4)
+        pc = np.broadcast_to(np.expand_dims(obj_pointcloud, 1), (nobj, T, P, 3))
+        pc = transf_point_array_np(transf, pc)                                      # (nobj, T, P, 3)
+        pc = np.swapaxes(pc, 0, 1).reshape((T, -1, 3))
+        dist = torch.cdist(torch.from_numpy(hv[b]).float(), torch.from_numpy(np.ascontiguousarray(pc)).float(), p=2)
+        ref[b] = dist.reshape(T, -1).min(dim=1).values.numpy()
+    mine = G.contact_min_dist(torch.from_numpy(hv), torch.from_numpy(traj), torch.from_numpy(pts)).numpy()
+    ratio = float(np.mean(ref < 0.005))
+    print(f"contact min dist: |ref-oracle| = {np.abs(ref - mine).max():.3e}  min {ref.min():.5f} contact ratio {ratio:.4f}"
+          f" (oracle {G.contact_ratio(torch.from_numpy(mine)):.4f})")
+    np.savez_compressed(os.path.join(OUT_DIR, "contact.npz"), hand_verts=hv, obj_traj=traj, obj_points=pts, min_dist=ref,
+                        contact_ratio=np.float64(ratio))
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
     sys.path.insert(0, REF_SRC)
     os.makedirs(OUT_DIR, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:  # e.g. `python -m oracle.capture_golden contact geometry`: only the named captures
+        for name in sys.argv[1:]:
+            globals()["capture_" + name]()
+        return
     capture_schedule()
     capture_forward("tiny", O.ARCH_TINY, B=2, T=16, ts=[0, 1, 500, 999])
     capture_forward("tiny_ragged", O.ARCH_TINY, B=3, T=21, ts=[7], nobj=3)
@@ -341,6 +377,7 @@ def main():
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()
+    capture_contact()
 
 
 if __name__ == "__main__":

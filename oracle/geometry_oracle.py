@@ -77,3 +77,15 @@ def h2o_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch
         near = torch.gather(pts, 1, idx[..., None].expand(T, V, 3))
         out[b] = (hand_verts[b] - near).norm(dim=-1)
     return out
+
+
+def contact_min_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_points: torch.Tensor, obj_num=None) -> torch.Tensor:
+    """Per-frame contact distance of the Contact-Ratio score (script/compute_score/compute_score_cr.py:122-149):
+    object points of all (real) objects are moved to the frame's pose and merged, then the smallest hand-vertex to
+    object-point distance of the frame is taken.  -> (B, T)"""
+    return h2o_dist(hand_verts, obj_traj, obj_points, obj_num).min(dim=-1).values
+
+
+def contact_ratio(min_dist: torch.Tensor, threshold: float = 0.005) -> float:
+    """compute_score_cr.py:282-283: share of frames whose contact distance is below 5 mm."""
+    return float((min_dist < threshold).double().mean())

@@ -1,4 +1,4 @@
-"""Rows 8(f)-1/-2: pose decode and hand->object distance.  CPU: oracle vs the reference's golden outputs.
+"""Rows 8(f)-1/-2/-4: pose decode, hand->object distance, Contact-Ratio frame distance.  CPU: oracle vs the reference's golden outputs.
 GPU: HIP kernels vs the same fixtures (tolerance 2e-6 abs on unit quaternions / 1e-6 abs on distances of ~0.05)."""
 import numpy as np
 import pytest
@@ -21,6 +21,37 @@ def test_oracle_h2o_matches_reference():
     out = G.h2o_dist(torch.from_numpy(fix["hand_verts"]), torch.from_numpy(fix["obj_traj"]), torch.from_numpy(fix["obj_points"]),
                      fix["obj_num"])
     np.testing.assert_allclose(out.numpy(), fix["h2o"], rtol=0, atol=1e-7)
+
+
+def test_oracle_contact_matches_reference():
+    """fixture = the reference's transform helpers + torch.cdist(...).min exactly as compute_score_cr.py:122-149 calls them;
+    cdist's matmul formulation is good to ~1e-6 here, hence the tolerance"""
+    fix = load_golden("contact.npz")
+    d = G.contact_min_dist(torch.from_numpy(fix["hand_verts"]), torch.from_numpy(fix["obj_traj"]), torch.from_numpy(fix["obj_points"]))
+    np.testing.assert_allclose(d.numpy(), fix["min_dist"], rtol=0, atol=3e-6)
+    assert G.contact_ratio(d) == pytest.approx(float(fix["contact_ratio"]), abs=1e-12)
+    assert 0.1 < float(fix["contact_ratio"]) < 0.9  # the fixture has frames on both sides of the 5 mm threshold
+
+
+@pytest.mark.gpu
+def test_hip_contact_min_dist():
+    from oakink2_tamf_amd import geometry
+
+    fix = load_golden("contact.npz")
+    hv, tr, pts = (torch.from_numpy(fix[k]).cuda() for k in ("hand_verts", "obj_traj", "obj_points"))
+    d = geometry.contact_min_dist(hv, tr, pts)
+    assert d.shape == fix["min_dist"].shape
+    np.testing.assert_allclose(d.cpu().numpy(), fix["min_dist"], rtol=0, atol=3e-6)
+    # bit-identical to the minimum of the per-vertex feature the same kernel produces
+    assert torch.equal(d, geometry.multi_object_h2o_dist(hv, tr, pts).min(dim=-1).values)
+    assert geometry.contact_ratio(d) == pytest.approx(float(fix["contact_ratio"]), abs=1e-12)
+    # ragged: per-clip object counts and clip lengths (`avai_len`)
+    ref = G.contact_min_dist(hv.cpu(), tr.cpu(), pts.cpu(), [2, 1, 2])
+    got = geometry.contact_min_dist(hv, tr, pts, [2, 1, 2])
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-6)
+    lens = [12, 7, 3]
+    keep = torch.arange(12)[None, :] < torch.tensor(lens)[:, None]
+    assert geometry.contact_ratio(got, lens) == pytest.approx(float((ref[keep] < 0.005).double().mean()), abs=1e-12)
 
 
 @pytest.mark.gpu

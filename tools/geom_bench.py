@@ -19,3 +19,8 @@ t = time.perf_counter()
 for _ in range(20): geometry.pose_repr_to_quat(pose)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
 print(f"pose_decode 64x196 frames: {dt*1e6:.1f} us ({pose.numel()*4/dt/1e9:.0f} GB/s read)")
+geometry.contact_min_dist(hv, tr, pts); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(n): cm = geometry.contact_min_dist(hv, tr, pts)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+print(f"contact_min_dist B={B}: {dt*1e3:.2f} ms  {pairs/dt/1e12:.2f} Tpair/s  contact ratio {geometry.contact_ratio(cm):.3f}")
