@@ -23,6 +23,8 @@ from typing import Dict, List
 
 import numpy as np
 
+from .formats import write_sample_npy
+
 _logger = logging.getLogger("oakink2_tamf_amd.launch.sample")
 PROG = "sample"
 
@@ -158,9 +160,7 @@ def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, co
         sample_np = sample.permute((0, 3, 1, 2)).detach().cpu().numpy().squeeze(3)  # (b, T, 99)
         for j, sample_id in enumerate(range(b0, b1)):
             if cfg["commit"]:
-                path = os.path.join(cfg["ckpt_path"], "sample", cfg["debug"].get("sample_save_offset", ""), f"{sample_id:06d}.npy")
-                os.makedirs(os.path.dirname(path), exist_ok=True)
-                np.save(path, sample_np[j].astype(np.float32))
+                write_sample_npy(cfg["ckpt_path"], cfg["debug"].get("sample_save_offset", ""), sample_id, sample_np[j])
             _logger.info("sample %06d", sample_id)
 
 

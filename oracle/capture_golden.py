@@ -351,6 +351,23 @@ def capture_contact():
                         contact_ratio=np.float64(ratio))
 
 
+def capture_collate():
+    """Row 8(f)-3: the reference's interaction_segment_collate (dataset/collate.py:33-58) on a ragged batch."""
+    from oakink2_tamf.dataset.collate import interaction_segment_collate
+
+    from .fixtures import ragged_clips
+
+    out = interaction_segment_collate(ragged_clips())
+    arrays = {}
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            arrays["t__" + k] = v.numpy()
+            arrays["dtype__" + k] = np.array(str(v.dtype))
+    arrays["listed_keys"] = np.array(sorted(k for k, v in out.items() if not isinstance(v, torch.Tensor)))
+    np.savez_compressed(os.path.join(OUT_DIR, "collate.npz"), **arrays)
+    print("collate:", {k: (tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else type(v).__name__ for k, v in out.items()})
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -378,6 +395,7 @@ def main():
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()
     capture_contact()
+    capture_collate()
 
 
 if __name__ == "__main__":
