@@ -27,6 +27,9 @@ struct GemmArgs {
   // bits 0-7: K-loop rotation stride per workgroup (0 = off); bits 8-11: L2 touch-prefetch distance in K tiles;
   // bit 12: ablation "no loads after tile 0"; bit 13: ablation "no compute"
   int krot;
+  // remainder splitting (set by the launcher): workgroups [0, n_full) take whole BM x BN tiles; the tiles left over
+  // after the last full round of the chip are cut into SPLIT column slices, one workgroup each (see gemm_kernel)
+  int n_full;
 };
 
 constexpr int GEMM_BKB = 128;  // bytes per tile row per K tile, every mode
@@ -423,9 +426,10 @@ struct GemmOcc {
 #ifdef TAMF_TIMELINE
 __device__ unsigned long long g_gemm_ts[8192 * 5];
 #endif
+// One BM x BN output tile at (m0, n0); `lb` is the tile's logical index (K rotation only), `bid` the hardware block id.
 template <class Op, int BM, int BN, int WGM, int WGN, class Epi>
-__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel(
-    const GemmArgs<Op> ga, const Epi epi) {
+TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, const int n0, const int lb, const int bid,
+                        char* smem) {
   TAMF_TS(ts0);
   constexpr int BKB = GEMM_BKB;
   constexpr int NT = WGM * WGN * 64;
@@ -440,16 +444,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   typedef GemmSmem<BM, BN> SM;
   constexpr int A_BYTES = BM * BKB;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, g = lane >> 4;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
-  const int ntn = ga.N / BN;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int n0 = (lb % ntn) * BN, m0 = (lb / ntn) * BM;
   const int M = ga.M;
   const int KT = (ga.K * Op::EB) / BKB;
   const char* Ab = (const char*)ga.A;
@@ -493,7 +492,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   const int pf = (ga.krot >> 8) & 0xF;
   const char* tbase = nullptr;
   {
-    const int peer = (blockIdx.x >> 3) & 7;
+    const int peer = (bid >> 3) & 7;
     if (wave < 2) {
       const int r = wave * 64 + lane;
       if (r < BM) {
@@ -585,9 +584,30 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   if (tsink == 0x9E3779B9u && ga.M < 0) Ct[0] = 1.0f;  // never true; keeps the touch loads from being optimised away
   epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
 #ifdef TAMF_TIMELINE
-  if (tid == 0 && blockIdx.x < 8192) {
-    unsigned long long* o = g_gemm_ts + blockIdx.x * 5;
+  if (tid == 0 && bid < 8192) {
+    unsigned long long* o = g_gemm_ts + bid * 5;
     o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = wall_clock64(); o[4] = tamf_hw_cu_id();
   }
 #endif
+}
+
+// Workgroup -> tile mapping.  A launch has n_full whole tiles (a multiple of the chip's resident workgroup count, so
+// they run as full rounds) and R left-over tiles; with SPLIT > 1 each left-over tile is processed as SPLIT column
+// slices of BN / SPLIT by SPLIT workgroups, so that the last, partial round is a round of short workgroups on every
+// CU instead of a round of full-length workgroups on a fraction of them.  Slices are dispatched last (highest block ids).
+template <class Op, int BM, int BN, int WGM, int WGN, class Epi, int SPLIT>
+__global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_PER_SIMD)) void gemm_kernel(
+    const GemmArgs<Op> ga, const Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntn = ga.N / BN;
+  const int bid = blockIdx.x;
+  if (SPLIT == 1 || bid < ga.n_full) {
+    const int lb = xcd_remap(bid, SPLIT == 1 ? (int)gridDim.x : ga.n_full);
+    gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, (lb / ntn) * BM, (lb % ntn) * BN, lb, bid, smem);
+  } else {
+    constexpr int BNS = BN / SPLIT;
+    const int j = xcd_remap(bid - ga.n_full, (int)gridDim.x - ga.n_full);
+    const int big = ga.n_full + j / SPLIT, sub = j % SPLIT;
+    gemm_tile<Op, BM, BNS, WGM, WGN, Epi>(ga, epi, (big / ntn) * BM, (big % ntn) * BN + sub * BNS, big, bid, smem);
+  }
 }
