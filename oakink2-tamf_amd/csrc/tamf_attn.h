@@ -113,8 +113,7 @@ struct AttnBlock {
     }
     float bm = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
                      fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    bm = groups_reduce<RedMax>(bm);
     const float m_new = fmaxf(m_run, bm);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
@@ -125,8 +124,7 @@ struct AttnBlock {
         st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - m_new);
         ps += st[t][r];
       }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
+    ps = groups_reduce<RedSum>(ps);
     l_run = l_run * alpha + ps;
     m_run = m_new;
 #pragma unroll

@@ -197,11 +197,43 @@ TAMF_DEV int vt_key_pos(int k) {
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------
-TAMF_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane reductions without LDS round trips (__shfl_xor compiles to ~6 VALU + ds_bpermute_b32 + an exposed LDS
+// latency per step): DPP modifiers inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.
+// `swap16(v)` returns (value of the even row, value of the odd row) of this lane's row pair in BOTH rows, `swap32(v)`
+// (lower half, upper half) in both halves, so a commutative op of the two components is the xor-16 / xor-32 step.
+template <int CTRL>
+TAMF_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140 };
+struct RedSum { static TAMF_DEV float op(float a, float b) { return a + b; } };
+struct RedMax { static TAMF_DEV float op(float a, float b) { return fmaxf(a, b); } };
+struct RedMin { static TAMF_DEV float op(float a, float b) { return fminf(a, b); } };
+// over the 4 lane groups g = lane >> 4 (lanes l, l^16, l^32, l^48); every lane gets the result.
+// (the two results are copied to scalars before the bit casts: __builtin_bit_cast straight from an element of the
+// returned vector reads element 0 twice with hipcc 7.2 - tools/micro/reduce_test.hip checks these on the GPU)
+template <class R>
+TAMF_DEV float groups_reduce(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  unsigned lo = a[0], hi = a[1];
+  v = R::op(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+  u = __builtin_bit_cast(unsigned, v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  lo = b[0];
+  hi = b[1];
+  return R::op(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+}
+// over all 64 lanes; every lane gets the result
+template <class R>
+TAMF_DEV float wave_reduce(float v) {
+  v = R::op(v, dpp_mov<DPP_XOR1>(v));
+  v = R::op(v, dpp_mov<DPP_XOR2>(v));
+  v = R::op(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+  v = R::op(v, dpp_mov<DPP_ROW_MIRROR>(v));
+  return groups_reduce<R>(v);
+}
+TAMF_DEV float wave_sum(float v) { return wave_reduce<RedSum>(v); }
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller (restated in oracle/mdm_oracle.py:philox_normal)

@@ -127,8 +127,7 @@ __global__ __launch_bounds__(256) void h2o_dist_kernel(const float* __restrict__
     }
   }
   if (frame_min) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fm = fminf(fm, __shfl_xor(fm, off, 64));
+    fm = wave_reduce<RedMin>(fm);
     if ((tid & 63) == 0) wmin[tid >> 6] = fm;
     __syncthreads();
     if (tid == 0) frame_min[(long)b * T + t] = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
