@@ -148,24 +148,19 @@ struct AttnBlock {
     } else {
       // bf16: B fragment element j of lane group g is P[key 4g + j] (j < 4) / P[key 16 + 4g + j - 4] (j >= 4);
       // V^T is stored with exactly that key order, so its A fragment is one 16-byte chunk per plane.
-      uint32_t hi[8];
-      float lo[8];
+      uint32_t wh[4], wl[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float pv = st[j >> 2][j & 3];
-        hi[j] = f2bf(pv);
-        lo[j] = pv - bf2f(hi[j]);
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = st[(2 * j) >> 2][(2 * j) & 3], p1 = st[(2 * j + 1) >> 2][(2 * j + 1) & 3];
+        if constexpr (Op::PREC == 2) {
+          split_bf16x3(p0, p1, wh[j], wl[j]);
+        } else {
+          wh[j] = pack_bf16(p0, p1);
+          wl[j] = wh[j];
+        }
       }
-      const bf16x8 ph = __builtin_bit_cast(bf16x8, make_int4((int)(hi[0] | (hi[1] << 16)), (int)(hi[2] | (hi[3] << 16)),
-                                                              (int)(hi[4] | (hi[5] << 16)), (int)(hi[6] | (hi[7] << 16))));
-      bf16x8 pl = ph;
-      if constexpr (Op::PREC == 2) {
-        uint32_t l2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) l2[j] = f2bf(lo[j]);
-        pl = __builtin_bit_cast(bf16x8, make_int4((int)(l2[0] | (l2[1] << 16)), (int)(l2[2] | (l2[3] << 16)),
-                                                   (int)(l2[4] | (l2[5] << 16)), (int)(l2[6] | (l2[7] << 16))));
-      }
+      const bf16x8 ph = __builtin_bit_cast(bf16x8, make_int4((int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]));
+      const bf16x8 pl = __builtin_bit_cast(bf16x8, make_int4((int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]));
 #pragma unroll
       for (int nt = 0; nt < NT16; ++nt) {
         // V^T is stored key-permuted (vt_key_pos): the fragment of lane group g is chunk g (hi) / 4 + g (lo) of row e

@@ -23,6 +23,18 @@ __device__ __forceinline__ unsigned long long tamf_hw_cu_id() {  // (XCC id << 3
 
 TAMF_DEV uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
 TAMF_DEV float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+// two floats -> packed bf16 pair (round to nearest even; one v_cvt_pk_bf16_f32), element 0 in the low half
+typedef float tamf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tamf_bf16x2 __attribute__((ext_vector_type(2)));
+TAMF_DEV uint32_t pack_bf16(float a, float b) {
+  const tamf_f32x2 f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tamf_bf16x2));
+}
+// bf16x3 split of a pair: hi = bf16(v), lo = bf16(v - hi); both packed, element 0 in the low half (6 VALU per pair)
+TAMF_DEV void split_bf16x3(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16(a, b);
+  lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u));
+}
 TAMF_DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
 TAMF_DEV int as_i(float v) { return __builtin_bit_cast(int, v); }
 
@@ -134,7 +146,7 @@ struct OpBF16 {
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t w[N / 2];
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) w[i] = f2bf(v[2 * i]) | (f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < N / 2; ++i) w[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
     store_bf16_vec<N>((char*)base + idx * 2, w);
   }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = (uint16_t)f2bf(v); }
@@ -156,20 +168,12 @@ struct OpBF16X3 {
   static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
   template <int N>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
-    uint32_t hi[N], w[N / 2];
-    float lo[N];
+    uint32_t wh[N / 2], wl[N / 2];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      hi[i] = f2bf(v[i]);
-      lo[i] = v[i] - bf2f(hi[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) w[i] = hi[2 * i] | (hi[2 * i + 1] << 16);
+    for (int i = 0; i < N / 2; ++i) split_bf16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
     char* p = (char*)base + byte_off(idx);
-    store_bf16_vec<N>(p, w);
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) w[i] = f2bf(lo[2 * i]) | (f2bf(lo[2 * i + 1]) << 16);
-    store_bf16_vec<N>(p + 64, w);
+    store_bf16_vec<N>(p, wh);
+    store_bf16_vec<N>(p + 64, wl);
   }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
     char* p = (char*)base + byte_off(idx);

@@ -226,16 +226,38 @@ struct EpiLN {
       ga[j] = gamma[c0 + j];
       be[j] = beta[c0 + j];
     }
-    for (int row = wave; row < BM; row += NW) {
+    // the residual rows of all of this wave's rows are requested first: issued inside the row loop each row would
+    // expose one full global-load latency (8 rows per wave = most of this epilogue's time)
+    constexpr int RPW = BM / NW;  // rows per wave
+    static_assert(BM % NW == 0, "rows per wave");
+    float rs[RPW][VPL];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int gr = m0 + wave + i * NW;
+      gr = gr < M ? gr : M - 1;
+      const float* rp = resid + (long)gr * BN + c0;
+      if constexpr (VPL % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < VPL; j += 4) {
+          const float4 t = *(const float4*)(rp + j);
+          rs[i][j] = t.x; rs[i][j + 1] = t.y; rs[i][j + 2] = t.z; rs[i][j + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) rs[i][j] = rp[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wave + i * NW;
       const int gr = m0 + row;
       if (gr >= M) break;
       float v[VPL];
-      const float* rp = resid + (long)gr * BN + c0;
       const float* cp = Ct + row * LDC + c0;
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
-        v[j] = (cp[j] + bi[j]) + rp[j];
+        v[j] = (cp[j] + bi[j]) + rs[i][j];
         s += v[j];
       }
       const float mean = wave_sum(s) * (1.0f / BN);

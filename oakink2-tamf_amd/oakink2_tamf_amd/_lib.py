@@ -55,6 +55,12 @@ def load() -> ctypes.CDLL:
     global _lib
     with _lock:
         if _lib is None:
+            override = os.environ.get("TAMF_LIB_OVERRIDE")  # A/B runs of two builds on one box (tools/ab_build.sh)
+            if override:
+                import torch  # noqa: F401
+
+                _lib = ctypes.CDLL(override)
+                return _lib
             build()
             # torch ships its own libamdhip64; import it first so that the library binds to the HIP runtime
             # instance torch uses (one runtime per process: shared device memory, streams, contexts).
