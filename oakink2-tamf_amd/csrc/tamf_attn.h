@@ -1,7 +1,8 @@
 // Multi-head self-attention over one clip's S = T + prefix tokens (full, unmasked softmax(QK^T)V per
 // (clip, head); interaction_segment_mdm.py:63-70,171 -> nn.MultiheadAttention).
 //
-// Workgroup = NW waves = NW tiles of 16 queries of one (clip, head); keys/values are streamed through LDS in
+// Workgroup = NW <= 16 waves = NW tiles of 16 queries of one (clip, head); a T = 196 clip (13 tiles) is one workgroup,
+// so its K/V are streamed once (34 us vs 36 us with two workgroups).  Keys/values are streamed through LDS in
 // blocks of 32 keys (LDS-DMA, double-buffered: block kb+1 is in flight while block kb is multiplied, see AttnBlock)
 // with an online softmax, so LDS and registers are bounded for every arithmetic mode.
 // Both products run "swapped" so that the softmax axis (keys) lies along the MFMA row index and each lane owns
@@ -182,7 +183,7 @@ __device__ unsigned long long g_attn_ts[8192 * 4];
 #endif
 
 template <class Op, int HD>
-__global__ __launch_bounds__(512) void attn_kernel(const AttnArgs<Op> aa) {
+__global__ __launch_bounds__(1024) void attn_kernel(const AttnArgs<Op> aa) {
   TAMF_TS(ts0);
   typedef AttnCfg<Op, HD> C;
   typedef AttnBlock<Op, HD> BLK;

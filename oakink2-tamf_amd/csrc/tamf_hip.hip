@@ -291,7 +291,7 @@ template <class Op>
 static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
   const int nqt = (aa.Sp + 15) / 16;
   static const int nw_env = []() { const char* e = getenv("TAMF_ATTN_NW"); return e ? atoi(e) : 0; }();
-  const int nw_max = (nw_env >= 1 && nw_env <= 8) ? nw_env : 8;
+  const int nw_max = (nw_env >= 1 && nw_env <= 16) ? nw_env : 16;  // one workgroup per (clip, head) up to 256 queries: K/V streamed once
   const int chunks = (nqt + nw_max - 1) / nw_max;
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
