@@ -16,6 +16,7 @@
 
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
+#include "tamf_gemm_pipe.h"
 #include "tamf_geom.h"
 #include "tamf_misc.h"
 
@@ -256,8 +257,37 @@ struct GemmLaunch {
 template <class Epi> struct EpiCanSplit { static constexpr bool value = false; };
 template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool value = true; };
 template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
+// TAMF_GEMM_PIPE: 1 = use the persistent pipelined kernel (tamf_gemm_pipe.h) where it applies
+static int g_gemm_pipe = []() {
+  const char* e = getenv("TAMF_GEMM_PIPE");
+  return e ? atoi(e) : 0;
+}();
+template <class Op, class Epi>
+struct PipeLaunch {
+  static hipError_t prepare() {
+    static int state = 0;  // 0 unknown, 1 ok, -1 unavailable
+    if (state == 0)
+      state = hipFuncSetAttribute((const void*)gemm_pipe_kernel<Op, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_SMEM) == hipSuccess ? 1 : -1;
+    return state == 1 ? hipSuccess : hipErrorInvalidValue;
+  }
+  static bool applies(const GemmArgs<Op>& ga) {
+    return ga.N % PIPE_BN == 0 && (ga.K * Op::EB) % GEMM_BKB == 0 && (ga.K * Op::EB) / GEMM_BKB >= 8 && ((ga.K * Op::EB) / GEMM_BKB) % 2 == 0 && ga.M > 0;
+  }
+  static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+    const int tiles = (ga.N / PIPE_BN) * ((ga.M + PIPE_BM - 1) / PIPE_BM), cus = g_wg_slots / 2;
+    hipLaunchKernelGGL((gemm_pipe_kernel<Op, Epi>), dim3(tiles < cus ? tiles : cus), dim3(PIPE_NW * 64), PIPE_SMEM, st, ga, epi);
+    return hipGetLastError();
+  }
+};
+template <class Op, class Epi> struct EpiHasPipe { static constexpr bool value = false; };
+template <class Op> struct EpiHasPipe<Op, EpiBiasAct<Op>> { static constexpr bool value = true; };
+
 template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+  if constexpr (EpiHasPipe<Op, Epi>::value) {
+    if (g_gemm_pipe && epi.rowadd == nullptr && PipeLaunch<Op, Epi>::applies(ga) && PipeLaunch<Op, Epi>::prepare() == hipSuccess)
+      return PipeLaunch<Op, Epi>::launch(ga, epi, st);
+  }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
 template <class Op>
