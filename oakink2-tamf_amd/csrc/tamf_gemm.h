@@ -30,6 +30,9 @@ struct GemmArgs {
   // remainder splitting (set by the launcher): workgroups [0, n_full) take whole BM x BN tiles; the tiles left over
   // after the last full round of the chip are cut into SPLIT column slices, one workgroup each (see gemm_kernel)
   int n_full;
+  // > 0: persistent launch - the grid is one round of workgroups and workgroup b walks tiles b, b + grid, b + 2 grid, ...
+  // (n_tiles in total), which gives every CU the same number of tiles +-1 where the hardware's greedy dispatch does not
+  int n_tiles;
 };
 
 constexpr int GEMM_BKB = 128;  // bytes per tile row per K tile, every mode
@@ -636,6 +639,18 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntn = ga.N / BN;
   const int bid = blockIdx.x;
+  if (SPLIT == 1 && ga.n_tiles > 0) {
+    const int G = gridDim.x;
+    for (int base = 0; base < ga.n_tiles; base += G) {
+      const int cnt = ga.n_tiles - base < G ? ga.n_tiles - base : G;
+      if (bid < cnt) {
+        const int lb = base + xcd_remap(bid, cnt);
+        gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, (lb / ntn) * BM, (lb % ntn) * BN, lb, bid, smem);
+        __syncthreads();  // the C tile (aliasing the stages) has been consumed before the next tile's first DMA
+      }
+    }
+    return;
+  }
   if (SPLIT == 1 || bid < ga.n_full) {
     const int lb = xcd_remap(bid, SPLIT == 1 ? (int)gridDim.x : ga.n_full);
     gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, (lb / ntn) * BM, (lb % ntn) * BN, lb, bid, smem);

@@ -198,6 +198,11 @@ static int g_gemm_split = []() {
   const char* e = getenv("TAMF_GEMM_SPLIT");
   return e ? atoi(e) : -1;
 }();
+// TAMF_GEMM_PERSIST: 0 = never use the persistent one-round grid
+static int g_gemm_persist = []() {
+  const char* e = getenv("TAMF_GEMM_PERSIST");
+  return e ? atoi(e) : 1;
+}();
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
 // resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch
@@ -244,7 +249,15 @@ struct GemmLaunch {
         if (split > 1) gb.n_full = n_full;
       }
     }
-    const dim3 grid(gb.n_full + (tiles - gb.n_full) * split), block(2 * WGN * 64);
+    gb.n_tiles = 0;
+    int nblk = gb.n_full + (tiles - gb.n_full) * split;
+    // more than one round, a partial last round and no slices: a persistent one-round grid balances the CUs (the hardware
+    // hands a freed slot to the next workgroup greedily; QKV's 1248 tiles ended up as 4..6 per CU instead of 4..5)
+    if (g_gemm_persist != 0 && split == 1 && BM == 128 && tiles > g_wg_slots && tiles % g_wg_slots != 0) {
+      gb.n_tiles = tiles;
+      nblk = g_wg_slots;
+    }
+    const dim3 grid(nblk), block(2 * WGN * 64);
     if constexpr (CAN_SPLIT) {
       if (split == 4) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi, 4>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
       if (split == 2) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi, 2>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
