@@ -242,7 +242,9 @@ struct GemmLaunch {
     if constexpr (CAN_SPLIT) {
       // tiles left over after the last full round: cut them 2- or 4-ways while every slice still gets a CU to itself
       // (measured: slices sharing a CU take as long as the whole tiles did, FFN1 93.5 -> 89 us with 2 x 128 slices)
-      const int n_full = (tiles / g_wg_slots) * g_wg_slots, rem = tiles - n_full, cus = g_wg_slots / 2;
+      // (a launch of less than one round is sliced as long as the slices fit the workgroup slots: two slices sharing a CU
+      // overlap each other's latencies, one whole tile alone on a CU does not)
+      const int n_full = (tiles / g_wg_slots) * g_wg_slots, rem = tiles - n_full, cus = n_full ? g_wg_slots / 2 : g_wg_slots;
       if (g_gemm_split != 0 && rem > 0) {
         split = (rem * 4 <= cus) ? 4 : (rem * 2 <= cus) ? 2 : 1;
         if (g_gemm_split > 0 && g_gemm_split < split) split = g_gemm_split;
@@ -270,6 +272,7 @@ struct GemmLaunch {
 template <class Epi> struct EpiCanSplit { static constexpr bool value = false; };
 template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool value = true; };
 template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
+template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
 // TAMF_GEMM_PIPE: 1 = use the persistent pipelined kernel (tamf_gemm_pipe.h) where it applies
 static int g_gemm_pipe = []() {
   const char* e = getenv("TAMF_GEMM_PIPE");
@@ -319,7 +322,7 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
