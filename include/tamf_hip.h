@@ -174,7 +174,7 @@ int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t 
 /* ---- kernel benchmarks / tuning (tools/kbench.py) ------------------------------------------------ */
 /* Average milliseconds of `iters` launches of one GEMM on random operands already resident in HBM.
  * epi_kind: 0 = 128x128 tile, bias + GELU (FFN1 shape); 1 = 128x128 tile, QKV epilogue (N = 3d);
- * 2 = 64xN tile, residual + LayerNorm.  krot: -1 = default tuning, >= 0 = GemmArgs::krot bits (csrc/tamf_gemm.h:
+ * 2 = 64xN tile, residual + LayerNorm; 3 = 128x128 tile, bias, fp32 output (FFN2 of the two-kernel form).  krot: -1 = default tuning, >= 0 = GemmArgs::krot bits (csrc/tamf_gemm.h:
  * K-loop rotation, L2 touch-prefetch distance, ablation flags). */
 int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                     int32_t iters, float* ms_out, void* stream);

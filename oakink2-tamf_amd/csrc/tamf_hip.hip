@@ -1176,6 +1176,9 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
     if (epi_kind == 2) {
       EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, 1e-5f};
       e = gemm_ln<Op>(ga, ep, st);
+    } else if (epi_kind == 3) {
+      EpiStoreF32 ep{vec, x, N, ACT_NONE};
+      e = gemm128<Op>(ga, ep, st);
     } else if (epi_kind == 1) {
       const int d = N / 3;
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
