@@ -298,12 +298,13 @@ def main():
         }
         if other:
             line["other_dtypes"] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (one host measurement, not one per scaling point)
             line["cpu_baseline"] = cpu_baseline(args.arch, sd, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     ctx.close()
     if world > 1:
+        dist.barrier()  # rank 0 was still profiling / printing
         dist.destroy_process_group()
 
 
