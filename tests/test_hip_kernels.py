@@ -55,7 +55,7 @@ def test_gemm_asymmetric_identity(hb, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(200, 128, 128), (333, 256, 1024), (130, 512, 512), (64, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(200, 128, 128), (333, 256, 1024), (130, 512, 512), (64, 512, 2048), (512, 512, 512), (1000, 512, 1024)])
 def test_gemm_residual_layernorm(hb, prec, M, N, K):
     g = torch.Generator().manual_seed(2)
     a = torch.randn(M, K, generator=g)
