@@ -147,6 +147,17 @@ int tamf_contact_min_dist(const float* hand_verts_dev, const float* obj_traj_dev
                           const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
                           float* min_dist_out_dev, void* stream);
 
+/* Point-in-closed-mesh test of the Solid-Intersection-Volume score (script/compute_score/compute_score_siv.py:128-153 ->
+ * dev_fn/external/libmesh/inside_mesh.py:8-149 check_mesh_contains, whose Cython TriangleHash is an acceleration structure
+ * only): float64, the reference's operation order, no fused multiply-adds - the result is bit-identical to numpy's.
+ * verts (V,3) f64, faces (F,3) int32, points (N,3) f64, all device; scale3 / translate3: HOST arrays of the reference's
+ * rescaling to the hash grid, scale = (resolution - 1) / (bbox_max - bbox_min), translate = 0.5 - scale * bbox_min over the
+ * vertices referenced by faces (inside_mesh.py:21-26); tri_workspace: 16 * F doubles (device scratch);
+ * contains_out (N,) uint8: 1 = inside. */
+int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, const double* points_dev,
+                       int64_t n_points, const double* scale3, const double* translate3, int32_t resolution,
+                       double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream);
+
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);
 /* Runs ONE denoiser step (DDPM update at t = n_steps/2, Philox noise; the sampler state is advanced by it) kernel by

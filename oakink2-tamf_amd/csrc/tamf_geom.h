@@ -133,3 +133,83 @@ __global__ __launch_bounds__(256) void h2o_dist_kernel(const float* __restrict__
     if (tid == 0) frame_min[(long)b * T + t] = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
   }
 }
+
+// ---- point-in-closed-mesh test of the SIV score ---------------------------------------------------
+// dev_fn/external/libmesh/inside_mesh.py:8-149 (+ triangle_hash.pyx, an acceleration structure only), float64 with the
+// reference's operation order and no fused multiply-adds, so that the booleans are bit-identical to numpy's.
+// Per triangle (rescaled to the 512-grid frame) 16 doubles are prepared once: t3.xy, the 2D edge matrix a00 a01 a10 a11,
+// sign/abs of its determinant, the normal's x, y, sign/abs of its z, t1.xy and t1.z * |n_z|.
+constexpr int MESH_TC = 16;
+__global__ void mesh_prepare_kernel(const double* __restrict__ verts, const int* __restrict__ faces, int F, double sx, double sy,
+                                    double sz, double tx, double ty, double tz, double* __restrict__ tc) {
+#pragma clang fp contract(off)
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double t[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double* v = verts + (long)faces[f * 3 + k] * 3;
+    t[k][0] = sx * v[0] + tx;
+    t[k][1] = sy * v[1] + ty;
+    t[k][2] = sz * v[2] + tz;
+  }
+  const double a00 = t[0][0] - t[2][0], a01 = t[1][0] - t[2][0], a10 = t[0][1] - t[2][1], a11 = t[1][1] - t[2][1];
+  const double det = a00 * a11 - a01 * a10;
+  const double v1x = t[2][0] - t[0][0], v1y = t[2][1] - t[0][1], v1z = t[2][2] - t[0][2];
+  const double v2x = t[1][0] - t[0][0], v2y = t[1][1] - t[0][1], v2z = t[1][2] - t[0][2];
+  const double nx = v1y * v2z - v1z * v2y, ny = v1z * v2x - v1x * v2z, nz = v1x * v2y - v1y * v2x;
+  const double an = fabs(nz), sn = nz > 0.0 ? 1.0 : (nz < 0.0 ? -1.0 : 0.0);
+  double* o = tc + (long)f * MESH_TC;
+  o[0] = t[2][0]; o[1] = t[2][1];
+  o[2] = a00; o[3] = a01; o[4] = a10; o[5] = a11;
+  o[6] = det > 0.0 ? 1.0 : (det < 0.0 ? -1.0 : 0.0);
+  o[7] = fabs(det);
+  o[8] = nx; o[9] = ny; o[10] = sn; o[11] = an;
+  o[12] = t[0][0]; o[13] = t[0][1];
+  o[14] = t[0][2] * an;
+  o[15] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void mesh_contains_kernel(const double* __restrict__ tc, int F, const double* __restrict__ pts,
+                                                            long N, double sx, double sy, double sz, double tx, double ty,
+                                                            double tz, double res, unsigned char* __restrict__ out) {
+#pragma clang fp contract(off)
+  constexpr int TILE = 64;
+  __shared__ double tile[TILE * MESH_TC];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  double qx = 0.0, qy = 0.0, qz = 0.0;
+  bool live = false;
+  if (i < N) {
+    qx = sx * pts[i * 3 + 0] + tx;
+    qy = sy * pts[i * 3 + 1] + ty;
+    qz = sz * pts[i * 3 + 2] + tz;
+    // inside the rescaled bounding box [0, res]^3 (:43) and inside the hash grid (cell index < res, triangle_hash.pyx:63-67)
+    live = qx >= 0.0 && qx <= res && qy >= 0.0 && qy <= res && qz >= 0.0 && qz <= res && qx < res && qy < res;
+  }
+  unsigned above = 0, below = 0;
+  for (int f0 = 0; f0 < F; f0 += TILE) {
+    const int nt = F - f0 < TILE ? F - f0 : TILE;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt * MESH_TC; k += blockDim.x) tile[k] = tc[(long)f0 * MESH_TC + k];
+    __syncthreads();
+    if (!live) continue;
+    for (int j = 0; j < nt; ++j) {
+      const double* c = tile + j * MESH_TC;
+      const double adet = c[7];
+      if (adet == 0.0) continue;
+      const double y0 = qx - c[0], y1 = qy - c[1];
+      const double u = (c[5] * y0 - c[3] * y1) * c[6];
+      const double v = (-c[4] * y0 + c[2] * y1) * c[6];
+      const double s = u + v;
+      if (!(0.0 < u && u < adet && 0.0 < v && v < adet && 0.0 < s && s < adet)) continue;
+      const double an = c[11];
+      if (an == 0.0) continue;
+      const double alpha = c[8] * (c[12] - qx) + c[9] * (c[13] - qy);
+      const double depth = c[14] + alpha * c[10];
+      const double zq = qz * an;
+      if (depth >= zq) ++above;
+      else if (depth < zq) ++below;
+    }
+  }
+  if (i < N) out[i] = (unsigned char)(live && (above & 1u) && (below & 1u));
+}

@@ -1262,6 +1262,23 @@ extern "C" int tamf_contact_min_dist(const float* hand_verts_dev, const float* o
   return h2o_launch(hand_verts_dev, obj_traj_dev, obj_points_dev, obj_num_dev, B, T, V, nobj, P, nullptr, min_dist_out_dev, stream);
 }
 
+extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, const double* points_dev,
+                                  int64_t n_points, const double* scale3, const double* translate3, int32_t resolution,
+                                  double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream) {
+  if (!verts_dev || !faces_dev || !points_dev || !scale3 || !translate3 || !tri_workspace_dev || !contains_out_dev)
+    return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  if (n_faces <= 0 || n_points <= 0 || resolution <= 1) return fail(nullptr, TAMF_ERR_INVALID, "bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mesh_prepare_kernel, grid1d(n_faces), dim3(256), 0, st, verts_dev, (const int*)faces_dev, n_faces, scale3[0],
+                     scale3[1], scale3[2], translate3[0], translate3[1], translate3[2], tri_workspace_dev);
+  hipLaunchKernelGGL(mesh_contains_kernel, grid1d(n_points), dim3(256), 0, st, tri_workspace_dev, n_faces, points_dev,
+                     (long)n_points, scale3[0], scale3[1], scale3[2], translate3[0], translate3[1], translate3[2],
+                     (double)resolution, contains_out_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   g_krot = krot;
   return 0;

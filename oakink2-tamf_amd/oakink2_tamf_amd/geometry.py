@@ -6,6 +6,8 @@ multi_object_h2o_dist  reference: SegmentRefineModel.multi_object_h2o_dist (mode
                        point2point_signed (model/loss/chamfer_distance.py:4-64) -> external chamfer_distance CUDA extension
 contact_min_dist       reference: transf_merge_obj_pointcloud + contact_min_cdist (script/compute_score/compute_score_cr.py:122-149),
 contact_ratio          the Contact-Ratio score built on it (:282-283, threshold 5 mm)
+mesh_contains          reference: check_mesh_contains (dev_fn/external/libmesh/inside_mesh.py:8-149 + Cython TriangleHash),
+solid_intersection_volume  the SIV score built on it (script/compute_score/compute_score_siv.py:128-153)
 All return torch tensors on the inputs' device; no CPU fallback."""
 from __future__ import annotations
 
@@ -24,6 +26,8 @@ def _bind():
     L.tamf_pose_decode.argtypes = [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
     L.tamf_h2o_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
     L.tamf_contact_min_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
+    L.tamf_mesh_contains.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+                                     c_void_p, c_void_p]
     return L
 
 
@@ -80,3 +84,41 @@ def contact_ratio(min_dist: torch.Tensor, valid_len: Optional[Sequence[int]] = N
         keep = torch.arange(d.shape[1], device=d.device)[None, :] < torch.as_tensor(list(valid_len), device=d.device)[:, None]
         d = d[keep]
     return float((d < threshold).double().mean())
+
+
+def mesh_contains(verts, faces, points: torch.Tensor, resolution: int = 512) -> torch.Tensor:
+    """verts (V,3), faces (F,3) of a closed triangle mesh, points (N,3) -> bool (N,): point inside the mesh, with the
+    reference's float64 arithmetic (bit-identical booleans).  The mesh may live on the host (numpy) or the device; the
+    bounding-box rescaling of inside_mesh.py:21-26 is computed on the host in float64 exactly as the reference does."""
+    import numpy as np
+
+    dev = require_gpu(points.device)
+    v_np = verts.detach().cpu().numpy() if isinstance(verts, torch.Tensor) else np.asarray(verts)
+    f_np = faces.detach().cpu().numpy() if isinstance(faces, torch.Tensor) else np.asarray(faces)
+    v_np = v_np.astype(np.float64)
+    tri = v_np[f_np].reshape(-1, 3)
+    bmin, bmax = tri.min(axis=0), tri.max(axis=0)
+    scale = np.ascontiguousarray((resolution - 1) / (bmax - bmin), dtype=np.float64)
+    translate = np.ascontiguousarray(0.5 - scale * bmin, dtype=np.float64)
+    v = torch.from_numpy(np.ascontiguousarray(v_np)).to(dev)
+    f = torch.from_numpy(np.ascontiguousarray(f_np.astype(np.int32))).to(dev)
+    p = points.to(device=dev, dtype=torch.float64).contiguous()
+    n = p.shape[0]
+    out = torch.empty(n, device=dev, dtype=torch.uint8)
+    if n == 0:
+        return out.bool()
+    ws = torch.empty(f.shape[0] * 16, device=dev, dtype=torch.float64)
+    with torch.cuda.device(dev):
+        _check(_bind().tamf_mesh_contains(c_void_p(v.data_ptr()), c_void_p(f.data_ptr()), int(f.shape[0]), c_void_p(p.data_ptr()), n,
+                                          scale.ctypes.data_as(c_void_p), translate.ctypes.data_as(c_void_p), int(resolution),
+                                          c_void_p(ws.data_ptr()), c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return out.bool()
+
+
+def solid_intersection_volume(hand_verts, hand_faces, obj_points_list, el_vols) -> float:
+    """SIV of one frame in cm^3: per object the interior voxel centres (already in the frame's pose) inside the hand mesh
+    times the voxel volume (compute_score_siv.py:128-153)."""
+    siv = 0.0
+    for pts, el_vol in zip(obj_points_list, el_vols):
+        siv += float(mesh_contains(hand_verts, hand_faces, pts).sum().item()) * float(el_vol) * (10 ** 6)
+    return siv

@@ -368,6 +368,37 @@ def capture_collate():
     print("collate:", {k: (tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else type(v).__name__ for k, v in out.items()})
 
 
+def capture_siv():
+    """Row 8(f)-4 (SIV): the reference's check_mesh_contains (dev_fn/external/libmesh/inside_mesh.py) with its Cython
+    TriangleHash built from the reference source by oracle/build_ref.sh into oracle/_ref/libmesh.  The package is assembled at
+    import time from the two directories (python files from the reference, the compiled module from oracle/_ref)."""
+    import importlib.util
+    from types import SimpleNamespace
+
+    from . import geometry_oracle as G
+    from .fixtures import siv_cases
+
+    ref_pkg = os.path.join(REF_SRC, "dev_fn", "external", "libmesh")
+    built = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libmesh")
+    assert any(n.startswith("triangle_hash") for n in os.listdir(built)), "run oracle/build_ref.sh first"
+    pkg = types.ModuleType("tamf_ref_libmesh")
+    pkg.__path__ = [built, ref_pkg]
+    sys.modules["tamf_ref_libmesh"] = pkg
+    spec = importlib.util.spec_from_file_location("tamf_ref_libmesh.inside_mesh", os.path.join(ref_pkg, "inside_mesh.py"))
+    inside_mesh = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = inside_mesh
+    spec.loader.exec_module(inside_mesh)
+
+    arrays = {}
+    for name, v, f, pts in siv_cases():
+        ref = inside_mesh.check_mesh_contains(SimpleNamespace(vertices=v, faces=f), pts)
+        mine = G.mesh_contains(v, f, pts)
+        print(f"siv {name}: {len(f)} faces, {len(pts)} points, inside {int(ref.sum())}, oracle mismatches {int((ref != mine).sum())}")
+        arrays[f"{name}/verts"], arrays[f"{name}/faces"], arrays[f"{name}/points"] = v, f.astype(np.int32), pts
+        arrays[f"{name}/contains"] = ref
+    np.savez_compressed(os.path.join(OUT_DIR, "siv.npz"), **arrays)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -396,6 +427,7 @@ def main():
     capture_geometry()
     capture_contact()
     capture_collate()
+    capture_siv()
 
 
 if __name__ == "__main__":

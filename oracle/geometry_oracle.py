@@ -89,3 +89,68 @@ def contact_min_dist(hand_verts: torch.Tensor, obj_traj: torch.Tensor, obj_point
 def contact_ratio(min_dist: torch.Tensor, threshold: float = 0.005) -> float:
     """compute_score_cr.py:282-283: share of frames whose contact distance is below 5 mm."""
     return float((min_dist < threshold).double().mean())
+
+
+def mesh_contains(verts, faces, points, resolution: int = 512):
+    """Point-in-closed-mesh test of the SIV score (dev_fn/external/libmesh/inside_mesh.py:8-149, used by
+    script/compute_score/compute_score_siv.py:128-153), float64 numpy, brute force over all triangles.
+
+    The reference rescales mesh and points to [0.5, resolution - 0.5]^3 (:21-26,140-142), finds for every point the triangles
+    whose xy projection STRICTLY contains it (:144-149 TriangleIntersector2d.check_triangles; the Cython TriangleHash in front of
+    it is only an acceleration structure: a triangle that strictly contains the point covers the point's grid cell, but the hash
+    drops points whose cell index reaches `resolution`, triangle_hash.pyx:63-67), compares the intersection depth of the
+    vertical ray with the point's z, both scaled by |n_z| (:82-110), and calls the point inside when the numbers of
+    intersections above-or-at and below are both odd (:60-77).  Returns a bool array."""
+    import numpy as np
+
+    verts = np.asarray(verts, dtype=np.float64)
+    faces = np.asarray(faces)
+    pts = np.asarray(points, dtype=np.float64)
+    tri = verts[faces]  # (F, 3, 3)
+    flat = tri.reshape(-1, 3)
+    bmin, bmax = flat.min(axis=0), flat.max(axis=0)
+    scale = (resolution - 1) / (bmax - bmin)
+    translate = 0.5 - scale * bmin
+    tri = scale * tri + translate
+    p = scale * pts + translate
+    contains = np.zeros(len(p), dtype=bool)
+    ok = np.all((0 <= p) & (p <= resolution), axis=1)
+    ok &= (p[:, 0].astype(np.int64) < resolution) & (p[:, 1].astype(np.int64) < resolution)  # hash cell range
+    idx = np.nonzero(ok)[0]
+    t1, t2, t3 = tri[:, 0], tri[:, 1], tri[:, 2]
+    # 2D containment terms per triangle (check_triangles): A = [t1 - t3, t2 - t3]^T in xy
+    a00, a01 = t1[:, 0] - t3[:, 0], t2[:, 0] - t3[:, 0]
+    a10, a11 = t1[:, 1] - t3[:, 1], t2[:, 1] - t3[:, 1]
+    det = a00 * a11 - a01 * a10
+    sdet, adet = np.sign(det), np.abs(det)
+    # depth terms (compute_intersection_depth)
+    v1, v2 = t3 - t1, t2 - t1
+    nrm = np.cross(v1, v2)
+    n2 = nrm[:, 2]
+    sn2, an2 = np.sign(n2), np.abs(n2)
+    for lo in range(0, len(idx), 4096):
+        ii = idx[lo:lo + 4096]
+        q = p[ii]
+        y0 = q[:, None, 0] - t3[None, :, 0]
+        y1 = q[:, None, 1] - t3[None, :, 1]
+        u = (a11[None] * y0 - a01[None] * y1) * sdet[None]
+        v = (-a10[None] * y0 + a00[None] * y1) * sdet[None]
+        s = u + v
+        hit = (adet[None] != 0.0) & (0 < u) & (u < adet[None]) & (0 < v) & (v < adet[None]) & (0 < s) & (s < adet[None])
+        alpha = nrm[None, :, 0] * (t1[None, :, 0] - q[:, None, 0]) + nrm[None, :, 1] * (t1[None, :, 1] - q[:, None, 1])
+        depth = t1[None, :, 2] * an2[None] + alpha * sn2[None]
+        zq = q[:, None, 2] * an2[None]
+        live = hit & (an2[None] != 0)  # depth is NaN for triangles with n_z == 0 (:97-100): neither comparison holds
+        above = live & (depth >= zq)
+        below = live & (depth < zq)
+        contains[ii] = (above.sum(axis=1) % 2 == 1) & (below.sum(axis=1) % 2 == 1)
+    return contains
+
+
+def solid_intersection_volume(hand_verts, hand_faces, obj_points_list, el_vols) -> float:
+    """compute_score_siv.py:128-153: per object, voxel centres of the object's interior (already moved to the frame's pose) that
+    fall inside the hand mesh, times the voxel volume, in cm^3 (x 1e6)."""
+    siv = 0.0
+    for pts, el_vol in zip(obj_points_list, el_vols):
+        siv += float(mesh_contains(hand_verts, hand_faces, pts).sum()) * float(el_vol) * (10 ** 6)
+    return siv

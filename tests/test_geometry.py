@@ -1,4 +1,4 @@
-"""Rows 8(f)-1/-2/-4: pose decode, hand->object distance, Contact-Ratio frame distance.  CPU: oracle vs the reference's golden outputs.
+"""Rows 8(f)-1/-2/-4: pose decode, hand->object distance, Contact-Ratio frame distance, SIV point-in-mesh.  CPU: oracle vs the reference's golden outputs.
 GPU: HIP kernels vs the same fixtures (tolerance 2e-6 abs on unit quaternions / 1e-6 abs on distances of ~0.05)."""
 import numpy as np
 import pytest
@@ -87,3 +87,40 @@ def test_hip_h2o_dist():
     ref = G.h2o_dist(hv, tr, pts)
     got = geometry.multi_object_h2o_dist(hv.cuda(), tr.cuda(), pts.cuda())
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-6)
+
+
+def _siv_cases():
+    fix = load_golden("siv.npz")
+    return [(n, fix[n + "/verts"], fix[n + "/faces"], fix[n + "/points"], fix[n + "/contains"]) for n in ("blob", "torus")]
+
+
+def test_oracle_mesh_contains_matches_reference():
+    """fixture = the reference's check_mesh_contains with its own Cython TriangleHash (oracle/build_ref.sh); booleans, exact"""
+    for name, v, f, p, ref in _siv_cases():
+        got = G.mesh_contains(v, f, p)
+        assert got.dtype == bool and np.array_equal(got, ref), name
+        assert 50 < ref.sum() < len(ref) // 2  # the fixture has points on both sides
+    # points outside the bounding box and the empty query
+    assert not G.mesh_contains(v, f, np.array([[10.0, 10.0, 10.0]])).any()
+    assert G.mesh_contains(v, f, np.zeros((0, 3))).shape == (0,)
+    # SIV in cm^3: count x voxel volume x 1e6
+    name, v, f, p, ref = _siv_cases()[0]
+    assert G.solid_intersection_volume(v, f, [p, p[:100]], [8e-9, 1e-9]) == pytest.approx((ref.sum() * 8e-9 + ref[:100].sum() * 1e-9) * 1e6)
+
+
+@pytest.mark.gpu
+def test_hip_mesh_contains():
+    from oakink2_tamf_amd import geometry
+
+    for name, v, f, p, ref in _siv_cases():
+        got = geometry.mesh_contains(v, f, torch.from_numpy(p).cuda())
+        assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), ref), name  # bit-exact against the reference
+    # a larger random query against the oracle, mesh given as device tensors
+    name, v, f, _, _ = _siv_cases()[1]
+    g = np.random.default_rng(5)
+    q = v.min(0) + g.random((50000, 3)) * (v.max(0) - v.min(0))
+    got = geometry.mesh_contains(torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda(), torch.from_numpy(q).cuda())
+    assert np.array_equal(got.cpu().numpy(), G.mesh_contains(v, f, q))
+    assert geometry.mesh_contains(v, f, torch.zeros(0, 3).cuda()).shape == (0,)
+    vol = geometry.solid_intersection_volume(v, f, [torch.from_numpy(q).cuda()], [1e-9])
+    assert vol == pytest.approx(float(G.mesh_contains(v, f, q).sum()) * 1e-9 * 1e6)

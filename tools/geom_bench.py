@@ -24,3 +24,14 @@ t = time.perf_counter()
 for _ in range(n): cm = geometry.contact_min_dist(hv, tr, pts)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
 print(f"contact_min_dist B={B}: {dt*1e3:.2f} ms  {pairs/dt/1e12:.2f} Tpair/s  contact ratio {geometry.contact_ratio(cm):.3f}")
+import numpy as np
+sys.path.insert(0, ROOT)
+from oracle.fixtures import icosphere
+mv, mf = icosphere(3)                       # 1280 faces (a closed MANO hand has 1554)
+mv = mv * np.array([0.05, 0.09, 0.03])
+q = (torch.rand(200000, 3, generator=g, dtype=torch.float64) - 0.5).cuda() * 0.2
+geometry.mesh_contains(mv, mf, q); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5): ins = geometry.mesh_contains(mv, mf, q)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+print(f"mesh_contains 200k points x {len(mf)} faces: {dt*1e3:.2f} ms ({q.shape[0]*len(mf)/dt/1e9:.1f} G point-triangle tests/s, f64), inside {int(ins.sum())}")
