@@ -147,6 +147,12 @@ int tamf_contact_min_dist(const float* hand_verts_dev, const float* obj_traj_dev
                           const int32_t* obj_num_dev, int32_t B, int32_t T, int32_t V, int32_t nobj, int32_t P,
                           float* min_dist_out_dev, void* stream);
 
+/* Object point clouds moved along their trajectories: out[o,t,j] = R(o,t) points[o,j] + tsl(o,t), (tsl | rot6d) = traj[o,t]
+ * (dev_fn/transform/transform_np.py:169-175 tslrot6d_to_transf_np + :36-53 transf_point_array_np, as called by
+ * compute_score_cr.py:122-137 and compute_score_siv.py:146).  traj (n_obj,T,9), points (n_obj,P,3), out (n_obj,T,P,3);
+ * is_f64: 0 = float32 buffers, 1 = float64 buffers. */
+int tamf_transform_points(const void* obj_traj_dev, const void* obj_points_dev, int32_t n_obj, int32_t T, int32_t P,
+                          int32_t is_f64, void* out_dev, void* stream);
 /* Point-in-closed-mesh test of the Solid-Intersection-Volume score (script/compute_score/compute_score_siv.py:128-153 ->
  * dev_fn/external/libmesh/inside_mesh.py:8-149 check_mesh_contains, whose Cython TriangleHash is an acceleration structure
  * only): float64, the reference's operation order, no fused multiply-adds - the result is bit-identical to numpy's.

@@ -213,3 +213,30 @@ __global__ __launch_bounds__(256) void mesh_contains_kernel(const double* __rest
   }
   if (i < N) out[i] = (unsigned char)(live && (above & 1u) && (below & 1u));
 }
+
+// ---- rigid transform of object point clouds along a trajectory (second half) ------------------------
+// out[o, t, j] = R(o, t) pts[o, j] + tsl(o, t) with (tsl | rot6d) = traj[o, t]  - tslrot6d_to_transf_np + transf_point_array_np
+// (dev_fn/transform/transform_np.py:169-175,36-53; rot6d_to_rotmat_np rotation_np.py:478-499: rows b1, b2, b1 x b2),
+// as used by transf_merge_obj_pointcloud (compute_score_cr.py:122-137) and the SIV query points (compute_score_siv.py:146).
+template <class T>
+__global__ void transform_points_kernel(const T* __restrict__ traj, const T* __restrict__ pts, T* __restrict__ out, int nT, int P) {
+  const int t = blockIdx.x, o = blockIdx.y;
+  const T* tr = traj + ((long)o * nT + t) * 9;
+  const T a0 = tr[3], a1 = tr[4], a2 = tr[5], c0 = tr[6], c1 = tr[7], c2 = tr[8];
+  const T n1 = max(sqrt(a0 * a0 + a1 * a1 + a2 * a2), (T)1e-12);
+  const T b1x = a0 / n1, b1y = a1 / n1, b1z = a2 / n1;
+  const T dp = b1x * c0 + b1y * c1 + b1z * c2;
+  T b2x = c0 - dp * b1x, b2y = c1 - dp * b1y, b2z = c2 - dp * b1z;
+  const T n2 = max(sqrt(b2x * b2x + b2y * b2y + b2z * b2z), (T)1e-12);
+  b2x /= n2; b2y /= n2; b2z /= n2;
+  const T b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+  const T tx = tr[0], ty = tr[1], tz = tr[2];
+  const T* pp = pts + (long)o * P * 3;
+  T* op = out + (((long)o * nT + t) * P) * 3;
+  for (int j = threadIdx.x; j < P; j += blockDim.x) {
+    const T x = pp[j * 3 + 0], y = pp[j * 3 + 1], z = pp[j * 3 + 2];
+    op[j * 3 + 0] = b1x * x + b1y * y + b1z * z + tx;
+    op[j * 3 + 1] = b2x * x + b2y * y + b2z * z + ty;
+    op[j * 3 + 2] = b3x * x + b3y * y + b3z * z + tz;
+  }
+}

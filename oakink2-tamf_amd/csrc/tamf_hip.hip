@@ -1262,6 +1262,21 @@ extern "C" int tamf_contact_min_dist(const float* hand_verts_dev, const float* o
   return h2o_launch(hand_verts_dev, obj_traj_dev, obj_points_dev, obj_num_dev, B, T, V, nobj, P, nullptr, min_dist_out_dev, stream);
 }
 
+extern "C" int tamf_transform_points(const void* obj_traj_dev, const void* obj_points_dev, int32_t n_obj, int32_t T, int32_t P,
+                                     int32_t is_f64, void* out_dev, void* stream) {
+  if (!obj_traj_dev || !obj_points_dev || !out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  if (n_obj <= 0 || T <= 0 || P <= 0 || n_obj > 65535) return fail(nullptr, TAMF_ERR_INVALID, "bad shape");
+  if (is_f64)
+    hipLaunchKernelGGL((transform_points_kernel<double>), dim3(T, n_obj), dim3(256), 0, (hipStream_t)stream, (const double*)obj_traj_dev,
+                       (const double*)obj_points_dev, (double*)out_dev, T, P);
+  else
+    hipLaunchKernelGGL((transform_points_kernel<float>), dim3(T, n_obj), dim3(256), 0, (hipStream_t)stream, (const float*)obj_traj_dev,
+                       (const float*)obj_points_dev, (float*)out_dev, T, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, const double* points_dev,
                                   int64_t n_points, const double* scale3, const double* translate3, int32_t resolution,
                                   double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream) {

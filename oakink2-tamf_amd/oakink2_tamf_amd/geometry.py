@@ -6,6 +6,7 @@ multi_object_h2o_dist  reference: SegmentRefineModel.multi_object_h2o_dist (mode
                        point2point_signed (model/loss/chamfer_distance.py:4-64) -> external chamfer_distance CUDA extension
 contact_min_dist       reference: transf_merge_obj_pointcloud + contact_min_cdist (script/compute_score/compute_score_cr.py:122-149),
 contact_ratio          the Contact-Ratio score built on it (:282-283, threshold 5 mm)
+transform_points       reference: tslrot6d_to_transf_np + transf_point_array_np (dev_fn/transform/transform_np.py:169-175,36-53)
 mesh_contains          reference: check_mesh_contains (dev_fn/external/libmesh/inside_mesh.py:8-149 + Cython TriangleHash),
 solid_intersection_volume  the SIV score built on it (script/compute_score/compute_score_siv.py:128-153)
 All return torch tensors on the inputs' device; no CPU fallback."""
@@ -26,6 +27,7 @@ def _bind():
     L.tamf_pose_decode.argtypes = [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
     L.tamf_h2o_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
     L.tamf_contact_min_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
+    L.tamf_transform_points.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     L.tamf_mesh_contains.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
                                      c_void_p, c_void_p]
     return L
@@ -122,3 +124,23 @@ def solid_intersection_volume(hand_verts, hand_faces, obj_points_list, el_vols) 
     for pts, el_vol in zip(obj_points_list, el_vols):
         siv += float(mesh_contains(hand_verts, hand_faces, pts).sum().item()) * float(el_vol) * (10 ** 6)
     return siv
+
+
+def transform_points(obj_traj: torch.Tensor, obj_points: torch.Tensor) -> torch.Tensor:
+    """obj_traj (..., T, 9) = [tsl | rot6d], obj_points (..., P, 3) in the object frame -> (..., T, P, 3) in the frame's pose;
+    float32 or float64 (taken from obj_traj)."""
+    dev = require_gpu(obj_traj.device)
+    dt = torch.float64 if obj_traj.dtype == torch.float64 else torch.float32
+    tr = obj_traj.to(device=dev, dtype=dt).contiguous()
+    pts = obj_points.to(device=dev, dtype=dt).contiguous()
+    lead = tr.shape[:-2]
+    assert pts.shape[:-2] == lead and tr.shape[-1] == 9 and pts.shape[-1] == 3
+    T, P = tr.shape[-2], pts.shape[-2]
+    n = 1
+    for v in lead:
+        n *= int(v)
+    out = torch.empty(tuple(lead) + (T, P, 3), device=dev, dtype=dt)
+    with torch.cuda.device(dev):
+        _check(_bind().tamf_transform_points(c_void_p(tr.data_ptr()), c_void_p(pts.data_ptr()), n, T, P, int(dt == torch.float64),
+                                             c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return out

@@ -343,12 +343,17 @@ def capture_contact():
         pc = np.swapaxes(pc, 0, 1).reshape((T, -1, 3))
         dist = torch.cdist(torch.from_numpy(hv[b]).float(), torch.from_numpy(np.ascontiguousarray(pc)).float(), p=2)
         ref[b] = dist.reshape(T, -1).min(dim=1).values.numpy()
+    # the transformed clouds themselves (row 8f-2, second half), float64 through the reference's helpers
+    t64, p64 = traj[0].astype(np.float64), pts[0].astype(np.float64)
+    moved = transf_point_array_np(tslrot6d_to_transf_np(t64), np.broadcast_to(np.expand_dims(p64, 1), (nobj, T, P, 3)))
+    moved_mine = G.transform_points(torch.from_numpy(t64), torch.from_numpy(p64)).numpy()
+    print(f"transform_points: |ref-oracle| = {np.abs(moved - moved_mine).max():.3e}")
     mine = G.contact_min_dist(torch.from_numpy(hv), torch.from_numpy(traj), torch.from_numpy(pts)).numpy()
     ratio = float(np.mean(ref < 0.005))
     print(f"contact min dist: |ref-oracle| = {np.abs(ref - mine).max():.3e}  min {ref.min():.5f} contact ratio {ratio:.4f}"
           f" (oracle {G.contact_ratio(torch.from_numpy(mine)):.4f})")
     np.savez_compressed(os.path.join(OUT_DIR, "contact.npz"), hand_verts=hv, obj_traj=traj, obj_points=pts, min_dist=ref,
-                        contact_ratio=np.float64(ratio))
+                        contact_ratio=np.float64(ratio), moved_clip0_f64=moved[:, :, ::25, :])
 
 
 def capture_collate():

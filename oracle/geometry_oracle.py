@@ -154,3 +154,10 @@ def solid_intersection_volume(hand_verts, hand_faces, obj_points_list, el_vols) 
     for pts, el_vol in zip(obj_points_list, el_vols):
         siv += float(mesh_contains(hand_verts, hand_faces, pts).sum()) * float(el_vol) * (10 ** 6)
     return siv
+
+
+def transform_points(obj_traj: torch.Tensor, obj_points: torch.Tensor) -> torch.Tensor:
+    """tslrot6d_to_transf_np + transf_point_array_np (dev_fn/transform/transform_np.py:169-175,36-53): obj_traj (..., T, 9),
+    obj_points (..., P, 3) -> (..., T, P, 3) = R p + t per frame."""
+    R = rot6d_to_rotmat(obj_traj[..., 3:9])  # (..., T, 3, 3), rows b1, b2, b3
+    return torch.einsum("...tij,...pj->...tpi", R, obj_points) + obj_traj[..., None, 0:3]

@@ -124,3 +124,27 @@ def test_hip_mesh_contains():
     assert geometry.mesh_contains(v, f, torch.zeros(0, 3).cuda()).shape == (0,)
     vol = geometry.solid_intersection_volume(v, f, [torch.from_numpy(q).cuda()], [1e-9])
     assert vol == pytest.approx(float(G.mesh_contains(v, f, q).sum()) * 1e-9 * 1e6)
+
+
+def test_oracle_transform_points_matches_reference():
+    """fixture: tslrot6d_to_transf_np + transf_point_array_np of the reference in float64 (every 25th point of clip 0)"""
+    fix = load_golden("contact.npz")
+    tr, pts = torch.from_numpy(fix["obj_traj"][0]).double(), torch.from_numpy(fix["obj_points"][0]).double()
+    got = G.transform_points(tr, pts)
+    assert got.shape == (2, 12, 700, 3)
+    np.testing.assert_allclose(got[:, :, ::25].numpy(), fix["moved_clip0_f64"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_hip_transform_points():
+    from oakink2_tamf_amd import geometry
+
+    fix = load_golden("contact.npz")
+    tr, pts = torch.from_numpy(fix["obj_traj"]), torch.from_numpy(fix["obj_points"])
+    got64 = geometry.transform_points(tr[0].double().cuda(), pts[0].double().cuda())
+    assert got64.dtype == torch.float64 and got64.shape == (2, 12, 700, 3)
+    np.testing.assert_allclose(got64[:, :, ::25].cpu().numpy(), fix["moved_clip0_f64"], rtol=0, atol=1e-14)
+    got32 = geometry.transform_points(tr.cuda(), pts.cuda())  # batched (B, nobj, ...) float32
+    assert got32.dtype == torch.float32 and got32.shape == (3, 2, 12, 700, 3)
+    ref = G.transform_points(tr.double(), pts.double())
+    np.testing.assert_allclose(got32.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
