@@ -115,6 +115,66 @@ def test_refine_trunk_golden(name, prec, tol):
     assert err < tol, (name, prec, err)
 
 
+def test_refine_forward_with_mano_layers():
+    """the reference's whole R forward (pose decode -> MANO -> hand->object distance -> trunk) with a stand-in MANO callable
+    (the assets are licence-gated): every stage is checked against the oracle's restatement of the same stage"""
+    from types import SimpleNamespace
+
+    from oakink2_tamf_amd.model.segment_refine_model import SegmentRefineModel
+    from oracle import geometry_oracle as G
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY_R
+    fix = load_golden("refine_tiny_r.npz")
+    B, T = fix["x_in"].shape[:2]
+    g = torch.Generator().manual_seed(11)
+    Wq, Wb = torch.randn(64, 778 * 3, generator=g) * 0.02, torch.randn(10, 778 * 3, generator=g) * 0.01
+
+    def fake_mano(sign):
+        def layer(pose_coeffs, betas):  # (T,16,4), (T,10) -> verts (T,778,3), joints (T,21,3): any smooth map will do
+            w = (Wq.to(pose_coeffs) * sign, Wb.to(pose_coeffs))
+            v = (pose_coeffs.reshape(pose_coeffs.shape[0], 64) @ w[0] + betas @ w[1]).reshape(-1, 778, 3)
+            return SimpleNamespace(verts=v, joints=v[:, :21])
+        return layer
+
+    m = SegmentRefineModel(None, latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers,
+                           num_heads=arch.num_heads, precision="f32", use_pc=True, mano_layer_rh=fake_mano(1.0),
+                           mano_layer_lh=fake_mano(-1.0))
+    sd = O.det_state_dict(arch, tag="tiny_r/w")
+    m.load_state_dict(sd)
+    m = m.to("cuda")
+    x_in = torch.from_numpy(fix["x_in"]) * 0.3
+    sides = ["rh" if int(v) == 0 else "lh" for v in fix["cond/hand_side"]]
+    traj = torch.from_numpy(fix["cond/obj_traj"])
+    nobj = traj.shape[1]
+    obj_list = [[f"o{k}" for k in range(nobj)], ["o0"]][:B] if B == 2 else [[f"o{k}" for k in range(nobj)]] * B
+    clouds = [torch.randn(len(o), 300, 3, generator=g).numpy() * 0.05 for o in obj_list]
+    batch = {"sample_pose_repr": x_in.cuda(), "hand_side": sides, "shape": torch.from_numpy(fix["cond/shape"]).cuda(),
+             "obj_embedding": torch.from_numpy(fix["cond/obj_embedding"]).cuda(), "obj_traj": traj.cuda(), "obj_list": obj_list,
+             "obj_pointcloud": clouds}
+    res = m(batch, with_refined_geometry=True)
+    # stage by stage on the CPU
+    tsl, quat = G.pose_decode(x_in.reshape(B * T, 99))
+    quat = quat.reshape(B, T, 16, 4)
+    hv = torch.stack([fake_mano(1.0 if s == "rh" else -1.0)(quat[b], torch.from_numpy(fix["cond/shape"][b])).verts
+                      + x_in[b, :, None, 0:3] for b, s in enumerate(sides)])
+    np.testing.assert_allclose(res["sample_hand_verts"].cpu().numpy(), hv.numpy(), rtol=0, atol=5e-6)
+    pts = torch.zeros(B, nobj, 300, 3)
+    for b, c in enumerate(clouds):
+        pts[b, : c.shape[0]] = torch.from_numpy(c)
+    h2o = G.h2o_dist(hv, traj, pts, [len(o) for o in obj_list])
+    np.testing.assert_allclose(res["sample_h2o_dist"].cpu().numpy(), h2o.numpy(), rtol=0, atol=5e-6)
+    cond = {"hand_side": sides, "shape": torch.from_numpy(fix["cond/shape"]), "obj_embedding": torch.from_numpy(fix["cond/obj_embedding"]),
+            "obj_traj": traj}
+    ref = O.refine_forward(sd, arch, x_in, h2o, cond)
+    np.testing.assert_allclose(res["refine_pose_repr"].cpu().numpy(), ref.numpy(), rtol=0, atol=5e-5)
+    assert res["refine_hand_verts"].shape == (B, T, 778, 3) and res["refine_h2o_dist"].shape == (B, T, 778)
+    # without MANO layers and without h2o_dist the module refuses
+    m2 = SegmentRefineModel(None, latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    with pytest.raises(KeyError):
+        m2.to("cuda")(batch)
+
+
 def test_cli_synthetic_end_to_end(tmp_path, monkeypatch):
     from oakink2_tamf_amd.launch import sample as S
     from conftest import ROOT

@@ -115,6 +115,25 @@ def test_refine_module_state_dict_keys():
     m.load_state_dict(sd)  # manotorch buffers of reference checkpoints are dropped
 
 
+def test_refine_module_mano_layers_are_not_state():
+    """MANO layers handed to the module stay outside its state dict (reference checkpoints carry mano_layer_* buffers that are
+    dropped on load); object point lists are zero padded on the object axis like the collate pads the trajectories"""
+    from oakink2_tamf_amd.model.segment_refine_model import SegmentRefineModel
+
+    class FakeMano(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("th_faces", torch.zeros(4, 3))
+
+    m = SegmentRefineModel(None, mano_layer_rh=FakeMano(), mano_layer_lh=FakeMano())
+    assert set(m.state_dict()) == set(O.state_dict_spec(O.ARCH_REFINE)) and m.mano_layer_rh is not None
+    pts, counts = SegmentRefineModel._pad_object_points([np.ones((1, 5, 3)), np.ones((3, 5, 3), np.float64)], "cpu")
+    assert pts.shape == (2, 3, 5, 3) and pts.dtype == torch.float32 and counts == [1, 3]
+    assert float(pts[0, 1:].abs().sum()) == 0.0 and float(pts[1].sum()) == 45.0
+    with pytest.raises(ValueError):
+        SegmentRefineModel._pad_object_points([np.ones((1, 5, 3)), np.ones((1, 6, 3))], "cpu")
+
+
 def test_cli_config_surface(tmp_path):
     from oakink2_tamf_amd.launch import sample as S
 
