@@ -1,5 +1,7 @@
 """GPU: the reference's call contracts end to end - model(x, t, batch=...), diffusion.p_sample_loop(model, ...),
 the R trunk - through the nn.Module mirror (oakink2_tamf_amd.model.*)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -173,6 +175,43 @@ def test_refine_forward_with_mano_layers():
     m2 = SegmentRefineModel(None, latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
     with pytest.raises(KeyError):
         m2.to("cuda")(batch)
+
+
+def test_refine_cli_end_to_end(tmp_path, monkeypatch):
+    """R-stage launcher: per-clip pickle in, save_dict.pkl tree out (reference layout), MANO through the factory hook"""
+    import pickle
+
+    from oakink2_tamf_amd.launch import formats, sample_refine
+    from oracle.fixtures import ragged_clips
+
+    clips = ragged_clips()
+    g = np.random.default_rng(2)
+    for c in clips:
+        c["sample_pose_repr"] = (g.standard_normal(c["pose_repr"].shape) * 0.3).astype(np.float32)
+        c["obj_pointcloud"] = (g.standard_normal((c["obj_traj"].shape[0], 200, 3)) * 0.05).astype(np.float32)
+    clips.append(dict(clips[0]))  # a duplicate info (reverse twin) is skipped
+    pkl = tmp_path / "clips.pkl"
+    with open(pkl, "wb") as f:
+        pickle.dump(clips, f)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.syspath_prepend(os.path.dirname(os.path.abspath(__file__)))
+    argv = ["--data.clips_pkl", str(pkl), "--mano.factory", "fake_mano:make", "--debug.sample_save_offset", "test/tiny__0001",
+            "--model.latent_dim", "128", "--model.ff_size", "256", "--model.num_layers", "2", "--model.num_heads", "2",
+            "--precision", "f32", "--commit"]
+    assert sample_refine.main(argv) == 0
+    ck = formats.ckpt_path("sample_refine", "main", cwd=str(tmp_path))
+    for c in clips[:3]:
+        d = formats.read_refine_sample(formats.refine_sample_path(ck, "test/tiny__0001", c["info"]))
+        T = c["pose_repr"].shape[0]
+        assert d["hand_side"] == c["hand_side"] and d["len"] == c["len"] and d["obj_list"] == c["obj_list"]
+        assert d["refine_pose_repr"].shape == (T, 99) and d["verts"].shape == (T, 778, 3) and d["joints"].shape == (T, 21, 3)
+        assert np.isfinite(d["refine_pose_repr"]).all() and d["faces"].shape == (1554, 3)
+        # residual form: the refined pose stays near its input for a randomly initialised small trunk
+        assert np.abs(d["refine_pose_repr"] - c["sample_pose_repr"]).max() < 5.0
+    # nothing is written without --commit
+    monkeypatch.chdir(tmp_path / "common")
+    assert sample_refine.main([a for a in argv if a != "--commit"]) == 0
+    assert not os.path.exists(tmp_path / "common" / "common")
 
 
 def test_cli_synthetic_end_to_end(tmp_path, monkeypatch):
