@@ -160,7 +160,8 @@ struct EpiQKV {
         for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
         Op::template store<8>(qk, (long)gr * (2 * d) + gn, v);
       }
-    } else {
+    } else if constexpr (Op::PREC == 0) {
+      // f32: V^T rows keep the natural key order; one thread = 8 consecutive keys of one feature
       for (int it = tid; it < (BM / 8) * BN; it += NT) {
         const int col = it % BN, rg = it / BN;
         const int gr0 = m0 + rg * 8;
@@ -172,13 +173,30 @@ struct EpiQKV {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Ct[(rg * 8 + j) * LDC + col] + bb;
-        const long rowb = ((long)(b * H + h) * hd + e) * Skp;
-        if constexpr (Op::PREC == 0) {
-          Op::template store<8>(vt, rowb + s0, v);
-        } else {  // keys s0..s0+3 and s0+4..s0+7 belong to two lane groups of the P.V fragment (vt_key_pos)
-          Op::template store<4>(vt, rowb + vt_key_pos<Op>(s0), v);
-          Op::template store<4>(vt, rowb + vt_key_pos<Op>(s0 + 4), v + 4);
-        }
+        Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
+      }
+    } else {
+      // bf16 modes: V^T is key-permuted (vt_key_pos): keys 4q .. 4q+3 of a 16-key group are 4 adjacent positions, the two
+      // groups of a 32-key block interleave in 8-byte steps.  One thread = one such run of 4 keys of one feature; a wave =
+      // 8 features x the 8 runs of one 32-row block, lanes ordered so that the 8 runs of a feature are adjacent: the stores
+      // of a wave are 8 segments of 64 bytes (hi, and again lo) instead of 64 scattered 8-byte pieces, and the column reads
+      // of the C tile are 2-way bank conflicts at worst.
+      static_assert(BM % 32 == 0 && BN % 8 == 0 && NT % 64 == 0, "V^T epilogue tiling");
+      constexpr int NB32 = BM / 32, WITER = NB32 * (BN / 8);  // wave-iterations of the tile
+      const int lane = tid & 63, wv = tid >> 6;
+      const int e_lo = lane >> 3, u_lo = (lane >> 2) & 1, gq = lane & 3;
+      for (int wi = wv; wi < WITER; wi += NT / 64) {
+        const int col = (wi / NB32) * 8 + e_lo, row0 = (wi % NB32) * 32 + u_lo * 16 + gq * 4;
+        const int gr0 = m0 + row0;
+        if (gr0 >= M) continue;
+        const int eg = n0 - 2 * d + col;
+        const int h = eg / hd, e = eg % hd;
+        const int b = gr0 / Sp, s0 = gr0 % Sp;
+        const float bb = bias[n0 + col];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;
+        Op::template store<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v);
       }
     }
   }
