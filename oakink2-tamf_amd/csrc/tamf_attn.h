@@ -115,21 +115,29 @@ struct AttnBlock {
     float bm = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
                      fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
     bm = groups_reduce<RedMax>(bm);
-    const float m_new = fmaxf(m_run, bm);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // Rescale on demand: the reference point m_run of a query only has to keep exp2(s - m_run) in range, it need not be
+    // the exact running maximum (softmax is invariant to it, the final 1 / l removes it).  The accumulators are rescaled
+    // only when some query of this wave sees its block maximum exceed m_run by more than 2^8 (always in the first block,
+    // rarely afterwards): the usual case costs no exp2 / 32 multiplies for alpha.  Wave-uniform decision.
+    constexpr float RESCALE_LOG2 = 8.0f;
+    if (__builtin_amdgcn_ballot_w64(bm > m_run + RESCALE_LOG2) != 0ull) {
+      const float m_new = fmaxf(m_run, bm);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int nt = 0; nt < NT16; ++nt) o[nt] *= alpha;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - m_new);
+        st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - m_run);
         ps += st[t][r];
       }
     ps = groups_reduce<RedSum>(ps);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int nt = 0; nt < NT16; ++nt) o[nt] *= alpha;
+    l_run += ps;
 
     // ---- O^T += V^T . P^T
     if constexpr (Op::PREC == 0) {
