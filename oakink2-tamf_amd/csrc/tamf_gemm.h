@@ -25,7 +25,7 @@ struct GemmArgs {
   int ldw;
   int M, N, K;
   // bits 0-7: K-loop rotation stride per workgroup (0 = off); bits 8-11: L2 touch-prefetch distance in K tiles;
-  // bit 12: ablation "no loads after tile 0"; bit 13: ablation "no compute"
+  // bit 12: ablation "no loads after tile 0"; bit 13: ablation "no compute"; bit 16: 4 x 2 XCD arrangement of the tile grid
   int krot;
   // remainder splitting (set by the launcher): workgroups [0, n_full) take whole BM x BN tiles; the tiles left over
   // after the last full round of the chip are cut into SPLIT column slices, one workgroup each (see gemm_kernel)
@@ -670,7 +670,17 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
     return;
   }
   if (SPLIT == 1 || bid < ga.n_full) {
-    const int lb = xcd_remap(bid, SPLIT == 1 ? (int)gridDim.x : ga.n_full);
+    const int nb = SPLIT == 1 ? (int)gridDim.x : ga.n_full;
+    const int nrb = nb / ntn;  // whole row blocks covered by these workgroups
+    if ((ga.krot & 0x10000) && nb == nrb * ntn && (nrb & 3) == 0 && (ntn & 1) == 0) {
+      // 4 x 2 arrangement of the XCDs over the tile grid (bit 16): an XCD owns a quarter of the row blocks and half of the
+      // column tiles, walked row-major - its concurrent tiles share half of W (instead of all of it) and their A panels
+      const int x = bid & 7, i = bid >> 3, R = nrb >> 2, C = ntn >> 1;
+      const int mb = (x >> 1) * R + i / C, nbk = (x & 1) * C + i % C;
+      gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, mb * BM, nbk * BN, mb * ntn + nbk, bid, smem);
+      return;
+    }
+    const int lb = xcd_remap(bid, nb);
     gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, (lb / ntn) * BM, (lb % ntn) * BN, lb, bid, smem);
   } else {
     constexpr int BNS = BN / SPLIT;

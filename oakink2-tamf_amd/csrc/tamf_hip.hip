@@ -238,6 +238,9 @@ struct GemmLaunch {
     const int ntn = ga.N / BN, ntm = (ga.M + BM - 1) / BM, tiles = ntn * ntm;
     GemmArgs<Op> gb = ga;
     gb.krot = krot_for(BM == 64);
+    // wide-N launches (FFN1: 16 column tiles): XCDs in a 4 x 2 arrangement over the tile grid - each L2 then serves half of W
+    // instead of all of it (FETCH_SIZE 162 -> 137 MB per launch, time unchanged); with few column tiles it would re-read A
+    if (g_krot < 0 && BM == 128 && ntn >= 8) gb.krot |= 0x10000;
     gb.n_full = tiles;
     int split = 1;
     if constexpr (CAN_SPLIT) {
