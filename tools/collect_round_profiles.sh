@@ -27,7 +27,7 @@ PY
 import csv, glob, json, sys, collections
 out, dt = sys.argv[1:3]
 CLASSES = [("EpiQKV", "gemm_qkv"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),
-           ("residual_ln_kernel", "ffn2_residual_ln"), ("512, 2, 4, EpiLN", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
+           ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
 def per_launch(ctr):
     f = glob.glob(f"{out}/pmc_{dt}_{ctr}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
