@@ -37,6 +37,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise TamfBuildError("hipcc not found: cannot build libtamf_hip.so")
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    # one builder at a time (the ranks of a multi-GPU launch all import this module): the others wait and then find it fresh
+    import fcntl
+
+    lock = open(LIB_PATH + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():
+            return LIB_PATH
+        return _build_locked(hipcc, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc: str, verbose: bool) -> str:
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            "-o", tmp, os.path.join(CSRC, "tamf_hip.hip")] + os.environ.get("TAMF_HIPCC_FLAGS", "").split()
