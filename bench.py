@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py - sampled motion frames/s of the MF-MDM 1000-step DDPM sampler on MI355X.
 
-Contract (one JSON line on rank 0):
+Contract (one JSON line on rank 0's stdout):
   python bench.py --gpus N --steps K --warmup W
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly
+  `python bench.py --gpus N ...`: with WORLD_SIZE unset the parent spawns its N ranks itself as fresh child processes
+  BEFORE anything has touched the GPU (a process that has initialised HIP is never re-executed).
 
 A "step" is ONE complete reverse loop (n_ddpm = 1000 DDPM steps, hipGraph-replayed) over one batch of synthetic
-clips: the workload of BASELINE.json configs[1] - arch_mdm_l, B = 64 clips per GPU, T = 196 frames, synthetic
-CLIP / object conditioning, device-Philox noise keyed by global clip id.  Clips are independent, so ranks shard them
-with no data-path collective (weak scaling: 64 clips per GPU); the only exchange is the RCCL all_gather of the
-sampled poses at the end of every loop, which is inside the timed region.
+clips.  Workload presets (--config): 2 = BASELINE.json configs[1] (arch_mdm_l, 64 clips per GPU, T = 196; the default),
+3 = configs[2] (32 clips per GPU: B = 256 over 8 GPUs), 5 = configs[4] (bf16, 64 clips per GPU: B = 512 over 8 GPUs).
+Clips are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is the RCCL
+all_gather of the sampled poses at the end of every loop, which is inside the timed region.
 
 value = (clips of all ranks) * T * K / (max-over-ranks wall time of the K timed loops), inputs resident in HBM.
+The line also carries, measured in the same run: `check` (max abs error of one denoiser evaluation against the oracle
+for every dtype reported), `roofline` (dominant kernel of the headline dtype, HIP events on the launch stream),
+`other_dtypes` (the same workload in the other arithmetic modes, among them the reference's own fp32) and
+`cpu_baseline` (the oracle on the host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,11 +35,21 @@ for p in (ROOT, os.path.join(ROOT, "oakink2-tamf_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}  # MI355X_MICROARCH.md: dense MFMA peaks
+# MI355X_MICROARCH.md: dense MFMA peaks.  The split modes issue three 16-bit MFMAs per algorithmic product; their
+# fraction is still quoted against the plain 16-bit peak (achieved = ALGORITHMIC flops / time).
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "bf16x3": 2500.0, "bf16": 2500.0}
+MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "bf16x3": 3, "bf16": 1}
 ARCHS = {
     "arch_mdm": dict(latent_dim=256, ff_size=1024, num_layers=8, num_heads=4),
     "arch_mdm_l": dict(latent_dim=512, ff_size=2048, num_layers=8, num_heads=4),
 }
+# --config presets: BASELINE.json configs[] (1-based numbering as in the task text: config 2 = configs[1])
+CONFIGS = {
+    2: dict(batch=64, dtype=None, label="BASELINE.json configs[1]: arch_mdm_l B=64 T=196 1000-step DDPM on 1 GPU"),
+    3: dict(batch=32, dtype=None, label="BASELINE.json configs[2]: arch_mdm_l B=256 T=196 1000-step DDPM sharded over 8 GPUs (32 clips per GPU)"),
+    5: dict(batch=64, dtype="bf16", label="BASELINE.json configs[4]: arch_mdm_l bf16 B=512 T=196 hipGraph 1000-step loop over 8 GPUs (64 clips per GPU)"),
+}
+DEFAULT_DTYPE = "f16x3"
 
 
 def flops_per_clip_step(arch, T):
@@ -42,16 +61,17 @@ def flops_per_clip_step(arch, T):
 
 def hbm_traffic(dtype, kernel, B, T):
     """HBM-side bytes per launch of `kernel` from the committed PMC measurement of this exact workload
-    (profiles/r01/hbm_traffic_<dtype>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
-    per the gfx950 correction of MI355X_MICROARCH.md).  None when no measurement matches."""
-    path = os.path.join(ROOT, "profiles", "r01", f"hbm_traffic_{dtype}.json")
-    try:
-        with open(path) as f:
-            m = json.load(f)
-        if m.get("B") == B and m.get("T") == T and kernel in m["kernels"]:
-            return m["kernels"][kernel]["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    (profiles/rNN/hbm_traffic_<dtype>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
+    per the gfx950 correction of MI355X_MICROARCH.md).  Newest round first; None when no measurement matches."""
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted((d for d in os.listdir(pdir) if d.startswith("r")), reverse=True) if os.path.isdir(pdir) else []:
+        try:
+            with open(os.path.join(pdir, rnd, f"hbm_traffic_{dtype}.json")) as f:
+                m = json.load(f)
+            if m.get("B") == B and m.get("T") == T and kernel in m["kernels"]:
+                return m["kernels"][kernel]["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
     return None
 
 
@@ -69,6 +89,17 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def synthetic_cond(B, T, seed, nobj=2):
     """Synthetic conditioning of SURVEY.md section 8(d): unit-normal CLIP / object embeddings and trajectories,
     alternating hand side, per-clip constant betas."""
@@ -84,11 +115,11 @@ def synthetic_cond(B, T, seed, nobj=2):
     }
 
 
-def cpu_baseline(arch_name, sd, T, n_ddpm, sample_B=16, timed=2):
+def cpu_baseline(arch_name, sd, B, T, n_ddpm, timed=5):
     """The oracle (torch-CPU restatement of the reference, proven equal to it on tests/golden) timed on the host
-    cores with the SAME weights as the GPU run: a bounded sample of the same workload - `sample_B` clips x
-    (1 warm-up + `timed`) denoiser+DDPM steps - extrapolated to the n_ddpm-step loop (every step does identical work).
-    This is the only place bench.py touches oracle/."""
+    cores with the SAME weights as the GPU run, at the workload's own (B, T): 1 warm-up + `timed` denoiser+DDPM steps
+    (BASELINE.md section 4), extrapolated to the n_ddpm-step loop (every step does identical work).
+    This and `oracle_check` are the only places bench.py touches oracle/."""
     import torch
 
     from oracle import mdm_oracle as O
@@ -96,46 +127,138 @@ def cpu_baseline(arch_name, sd, T, n_ddpm, sample_B=16, timed=2):
     arch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[arch_name]
     cores = usable_cores()
     torch.set_num_threads(cores)
-    cond = synthetic_cond(sample_B, T, seed=12345)
+    cond = synthetic_cond(B, T, seed=12345)
     tab = O.make_tables(n_ddpm, "cosine")
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(sample_B, 99, 1, T, generator=g)
+    x = torch.randn(B, 99, 1, T, generator=g)
     times = []
     with torch.no_grad():
         for it in range(1 + timed):
             i = n_ddpm - 1 - it
             t0 = time.perf_counter()
-            x0 = O.denoiser_forward(sd, arch, x, torch.full((sample_B,), i, dtype=torch.long), cond)
+            x0 = O.denoiser_forward(sd, arch, x, torch.full((B,), i, dtype=torch.long), cond)
             x = O.ddpm_step(tab, x, x0, i, torch.randn(x.shape, generator=g))
             times.append(time.perf_counter() - t0)
     step_s = sum(times[1:]) / timed
     return {
-        "value": sample_B * T / (step_s * n_ddpm),
+        "value": B * T / (step_s * n_ddpm),
         "unit": "frames/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{sample_B} clips x T={T}, {timed} timed denoiser+DDPM steps after 1 warm-up ({step_s * 1e3:.0f} ms/step), "
+        "cpu_model": cpu_model(),
+        "sample": f"{B} clips x T={T}, {timed} timed denoiser+DDPM steps after 1 warm-up ({step_s * 1e3:.0f} ms/step), "
         f"extrapolated to {n_ddpm} steps; conditioning recomputed every step as the reference does",
     }
 
 
-def main():
+def oracle_reference(arch_name, sd, cond, x, t, n_check):
+    """oracle.denoiser_forward on the first n_check clips of the bench batch (outside every timed region)."""
+    import torch
+
+    from oracle import mdm_oracle as O
+
+    arch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[arch_name]
+    sub = {k: (v[:n_check].cpu() if hasattr(v, "cpu") else list(v[:n_check])) for k, v in cond.items()}
+    with torch.no_grad():
+        return O.denoiser_forward(sd, arch, x[:n_check].cpu(), t[:n_check].cpu(), sub)
+
+
+class HipSampler:
+    """The product path: one library context of one arithmetic mode, conditioning resident in HBM."""
+
+    def __init__(self, arch, sd, B, T, N, dtype, dev, tab, use_graph=True):
+        from oakink2_tamf_amd.hip_backend import TamfContext
+
+        self.ctx = TamfContext(arch, B, T, precision=dtype, device=dev)
+        self.ctx.load_state_dict(sd, max_timesteps=max(N, 1000))
+        self.ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+        self.use_graph = use_graph
+
+    def set_cond(self, cond_dev):
+        self.ctx.set_cond(cond_dev["text_embedding"], cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"],
+                          cond_dev["obj_traj"])
+
+    def sample(self, seed, clip0, out):
+        self.ctx.sample_loop(noise=None, seed=seed, clip_id_base=clip0, use_graph=self.use_graph, out=out)
+
+    def denoise(self, x, t):
+        return self.ctx.denoise(x, t)
+
+    def step_profile(self):
+        return self.ctx.step_profile()
+
+    @property
+    def kernels_per_step(self):
+        return self.ctx.step_kernel_count
+
+    def close(self):
+        self.ctx.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not initialised the
+    GPU and never will), wait for them, exit with the worst return code.  Rank 0's stdout is the JSON line."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default=os.environ.get("TAMF_BENCH_DTYPE", "bf16x3"), choices=list(PEAK_TFLOPS))
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json workload preset")
+    ap.add_argument("--dtype", default=os.environ.get("TAMF_BENCH_DTYPE"), choices=list(PEAK_TFLOPS))
     ap.add_argument("--arch", default="arch_mdm_l", choices=list(ARCHS))
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the preset's)")
     ap.add_argument("--frames", type=int, default=196)
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--check-clips", type=int, default=2, help="clips of the in-run oracle check (0 = off)")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile of one step here (json)")
-    ap.add_argument("--also", default="bf16", help="comma list of extra dtypes measured with 1 loop each (reported under other_dtypes); '' = none")
-    args = ap.parse_args()
+    ap.add_argument("--also", default=None,
+                    help="comma list of extra dtypes measured with 1 loop each on 1 GPU (other_dtypes); default: all other modes; '' = none")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU test of the launch/gather path (needs --sampler)")
+    ap.add_argument("--sampler", default=None, help="test hook: module:callable replacing the HIP sampler (tests/bench_stub.py); never set on a GPU run")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = preset["batch"]
+    if args.dtype is None:
+        args.dtype = preset["dtype"] or DEFAULT_DTYPE
+    if args.also is None:
+        args.also = ",".join(d for d in PEAK_TFLOPS if d != args.dtype)
+    return args
 
-    import numpy as np
+
+def main(argv=None, sampler_factory=None):
+    """sampler_factory(arch, sd, B, T, N, dtype, dev, tab) -> object with the HipSampler interface; the default is the
+    HIP path.  The CPU test of the multi-rank plumbing passes a stub (tests/test_bench_main_gloo.py)."""
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (before any GPU call in this process)
+        raise SystemExit(spawn_ranks(args.gpus, argv))
+
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
@@ -143,41 +266,53 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if sampler_factory is None and args.sampler:
+        import importlib
+
+        mod, attr = args.sampler.split(":")
+        sampler_factory = getattr(importlib.import_module(mod), attr)
+    stub = sampler_factory is not None
+    if stub and args.backend == "gloo":
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dev.type == "cuda":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from oakink2_tamf_amd import shard
-    from oakink2_tamf_amd.hip_backend import TamfContext
     from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
     from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
 
+    factory = sampler_factory or HipSampler
     arch = ARCHS[args.arch]
     B, T, N = args.batch, args.frames, args.ddpm_steps
     # random-init weights of the named architecture (PyTorch default initialisers, fixed seed; identical on all ranks)
     torch.manual_seed(0)
     sd = InterationSegmentMDM(**arch).state_dict()
-    ctx = TamfContext(arch, B, T, precision=args.dtype, device=dev)
-    ctx.load_state_dict(sd, max_timesteps=max(N, 1000))
     tab = create_gaussian_diffusion(diffusion_steps=N, noise_schedule="cosine")
-    ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+    sampler = factory(arch, sd, B, T, N, args.dtype, dev, tab, use_graph=not args.no_graph)
     clip0 = shard.clip_id_base(rank, B)
     cond = synthetic_cond(B, T, seed=1000 + rank)
     cond_dev = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in cond.items()}
     out = torch.empty(B, 99, 1, T, device=dev)
     gathered = torch.empty(world * B, 99, 1, T, device=dev) if world > 1 else None
 
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
     def one_loop(seed):
         # the complete path: step-invariant conditioning precompute + n_ddpm-step reverse loop + result gather
-        ctx.set_cond(cond_dev["text_embedding"], cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"],
-                     cond_dev["obj_traj"])
-        ctx.sample_loop(noise=None, seed=seed, clip_id_base=clip0, use_graph=not args.no_graph, out=out)
+        sampler.set_cond(cond_dev)
+        sampler.sample(seed, clip0, out)
         if world > 1:
             shard.gather_clips(out, gathered)
         return gathered if world > 1 else out
@@ -185,7 +320,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     for w in range(args.warmup):
         one_loop(1000 + w)
@@ -200,17 +335,37 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     finite = bool(torch.isfinite(res).all().item())
+    # what every rank sampled, as seen by the collective (printed by rank 0)
+    rank_info = {"rank": rank, "clips": [clip0, clip0 + B], "device": str(dev)}
+    if world > 1:
+        infos = [None] * world
+        dist.all_gather_object(infos, rank_info)
+        world_seen = dist.get_world_size()
+    else:
+        infos, world_seen = [rank_info], 1
+
+    # in-run parity: one denoiser evaluation of the first clips of this batch against the oracle, per dtype reported
+    check = {}
+    check_in = None
+    if rank == 0 and args.check_clips > 0 and not stub:
+        nc = min(args.check_clips, B)
+        g = torch.Generator().manual_seed(4242)
+        xc = torch.randn(B, 99, 1, T, generator=g)
+        tc = torch.full((B,), N // 2, dtype=torch.long)
+        ref = oracle_reference(args.arch, sd, cond, xc, tc, nc)
+        check_in = (xc, tc, ref, nc)
+        sampler.set_cond(cond_dev)
+        got = sampler.denoise(xc.to(dev), tc.to(dev))[:nc].cpu()
+        check[args.dtype] = float((got - ref).abs().max())
 
     # dominant kernel, measured live with HIP events on the launch stream (rank 0)
     roofline = None
-    prof_rows = None
-    if rank == 0:
-        ctx.set_cond(cond_dev["text_embedding"], cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"],
-                     cond_dev["obj_traj"])
+    if rank == 0 and not stub:
+        sampler.set_cond(cond_dev)
         agg = {}
         reps = 5
         for r in range(reps + 1):
-            rows = ctx.step_profile()
+            rows = sampler.step_profile()
             if r == 0:
                 continue  # warm-up
             for name, ms, fl in rows:
@@ -229,6 +384,8 @@ def main():
         roofline = {
             "bound": "mfma",
             "kernel": dom["kernel"],
+            "dtype": args.dtype,
+            "mfma_per_product": MFMA_PER_PRODUCT[args.dtype],
             "achieved": dom["tflops"],
             "peak": peak,
             "unit": "TFLOP/s",
@@ -236,30 +393,33 @@ def main():
             "traffic": hbm_traffic(args.dtype, dom["kernel"], B, T),
             "avg_launch_ms": dom["avg_ms"],
             "share_of_step": dom["share"],
+            "attention": next(({"avg_launch_ms": r["avg_ms"], "tflops": r["tflops"], "frac": r["tflops"] / peak}
+                              for r in prof_rows if r["kernel"].startswith("attention")), None),
         }
         if args.profile_out:
             with open(args.profile_out, "w") as f:
                 json.dump({"dtype": args.dtype, "B": B, "T": T, "step_ms_eventsum": step_ms, "kernels": prof_rows}, f, indent=1)
 
-    # secondary dtypes: one warm-up + one timed loop each on rank 0's shard only (context, not the headline)
+    # the other arithmetic modes: one warm-up + one timed loop each on rank 0's shard only (context, not the headline)
     other = {}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not stub:
         for dt in [d for d in args.also.split(",") if d and d != args.dtype]:
-            c2 = TamfContext(arch, B, T, precision=dt, device=dev)
-            c2.load_state_dict(sd, max_timesteps=max(N, 1000))
-            c2.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
-            c2.set_cond(cond_dev["text_embedding"], cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"],
-                        cond_dev["obj_traj"])
-            c2.sample_loop(noise=None, seed=1, clip_id_base=clip0, out=out)
-            torch.cuda.synchronize(dev)
+            s2 = HipSampler(arch, sd, B, T, N, dt, dev, tab)
+            s2.set_cond(cond_dev)
+            s2.sample(1, clip0, out)
+            sync()
             t1 = time.perf_counter()
-            c2.sample_loop(noise=None, seed=2, clip_id_base=clip0, out=out)
-            torch.cuda.synchronize(dev)
+            s2.sample(2, clip0, out)
+            sync()
             dt_s = time.perf_counter() - t1
+            tf = flops_per_clip_step(arch, T) * B * N / dt_s / 1e12
             other[dt] = {"value": B * T / dt_s, "unit": "frames/s", "ms_per_ddpm_step": dt_s / N * 1e3,
-                         "whole_path_tflops": flops_per_clip_step(arch, T) * B * N / dt_s / 1e12,
-                         "note": "same workload, 1 timed loop; max |err| vs reference in DESIGN.md section 2"}
-            c2.close()
+                         "whole_path_tflops": tf, "whole_path_frac_of_peak": tf / PEAK_TFLOPS[dt],
+                         "note": "same workload, 1 timed loop after 1 warm-up loop"}
+            if check_in is not None:
+                xc, tc, ref, nc = check_in
+                check[dt] = float((s2.denoise(xc.to(dev), tc.to(dev))[:nc].cpu() - ref).abs().max())
+            s2.close()
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -281,14 +441,17 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (random-init weights of the named arch, N(0,1) CLIP/object conditioning, device Philox noise)",
             "config": {
-                "workload": f"{args.arch} B={B}/GPU T={T} {N}-step DDPM (BASELINE.json configs[1]); step = one full reverse loop",
+                "workload": f"{args.arch} B={B}/GPU T={T} {N}-step DDPM ({CONFIGS[args.config]['label']}); step = one full reverse loop",
+                "preset": args.config,
                 "clips_per_gpu": B,
                 "frames": T,
                 "ddpm_steps": N,
                 "global_clips": world * B,
                 "parallelism": f"clip-sharded x{world}, RCCL all_gather of results" if world > 1 else "single GPU",
+                "world_size_seen": world_seen,
+                "rank_clip_ranges": [i["clips"] for i in sorted(infos, key=lambda i: i["rank"])],
                 "hipgraph": not args.no_graph,
-                "kernels_per_ddpm_step": ctx.step_kernel_count,
+                "kernels_per_ddpm_step": sampler.kernels_per_step,
             },
             "ms_per_ddpm_step": elapsed / args.steps / N * 1e3,
             "whole_path_tflops": whole_tflops,
@@ -296,17 +459,21 @@ def main():
             "finite": finite,
             "roofline": roofline,
         }
+        if check:
+            line["check"] = {"max_abs_err_vs_oracle": check, "what": f"one denoiser evaluation (t={N // 2}) of the first "
+                             f"{min(args.check_clips, B)} clips of the bench batch vs oracle.denoiser_forward (fp32 torch-CPU restatement of the reference), outputs O(1)"}
         if other:
             line["other_dtypes"] = other
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (one host measurement, not one per scaling point)
-            line["cpu_baseline"] = cpu_baseline(args.arch, sd, T, N)
+        if not args.no_cpu_baseline and world == 1 and not stub:  # at N = 1 only (one host measurement, not one per scaling point)
+            line["cpu_baseline"] = cpu_baseline(args.arch, sd, B, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
-    ctx.close()
+        print(json.dumps(line), flush=True)
+    sampler.close()
     if world > 1:
         dist.barrier()  # rank 0 was still profiling / printing
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -48,7 +48,9 @@ typedef enum tamf_status {
 typedef enum tamf_precision {
   TAMF_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate (parity mode) */
   TAMF_PREC_BF16 = 1,   /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate */
-  TAMF_PREC_BF16X3 = 2  /* split-bf16 (hi+lo) operands, 3 bf16 MFMAs per product: ~2^-17 relative operand error */
+  TAMF_PREC_BF16X3 = 2, /* split-bf16 (hi+lo) operands, 3 bf16 MFMAs per product: ~2^-17 relative operand error */
+  TAMF_PREC_F16X3 = 3   /* split-fp16 (hi+lo) operands, 3 f16 MFMAs per product: ~2^-22 relative operand error (fp32: 2^-24),
+                           operands limited to |v| <= 65504 */
 } tamf_precision;
 
 typedef enum tamf_model_kind {

@@ -161,26 +161,21 @@ struct AttnBlock {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float p0 = st[(2 * j) >> 2][(2 * j) & 3], p1 = st[(2 * j + 1) >> 2][(2 * j + 1) & 3];
-        if constexpr (Op::PREC == 2) {
-          split_bf16x3(p0, p1, wh[j], wl[j]);
-        } else {
-          wh[j] = pack_bf16(p0, p1);
-          wl[j] = wh[j];
-        }
+        Op::split2(p0, p1, wh[j], wl[j]);
       }
-      const bf16x8 ph = __builtin_bit_cast(bf16x8, make_int4((int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]));
-      const bf16x8 pl = __builtin_bit_cast(bf16x8, make_int4((int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]));
+      const int4 ph = make_int4((int)wh[0], (int)wh[1], (int)wh[2], (int)wh[3]);
+      const int4 pl = make_int4((int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]);
 #pragma unroll
       for (int nt = 0; nt < NT16; ++nt) {
         // V^T is stored key-permuted (vt_key_pos): the fragment of lane group g is chunk g (hi) / 4 + g (lo) of row e
         const int e = nt * 16 + lr;
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, *(const int4*)(Vs + e * C::VSTR + vswz(g, e) * 16));
-        if constexpr (Op::PREC == 2) {
-          const bf16x8 vl = __builtin_bit_cast(bf16x8, *(const int4*)(Vs + e * C::VSTR + vswz(4 + g, e) * 16));
-          o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[nt], 0, 0, 0);
-          o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[nt], 0, 0, 0);
+        const int4 vh = *(const int4*)(Vs + e * C::VSTR + vswz(g, e) * 16);
+        if constexpr (Op::SPLIT) {
+          const int4 vl = *(const int4*)(Vs + e * C::VSTR + vswz(4 + g, e) * 16);
+          o[nt] = Op::mfma1(vl, ph, o[nt]);
+          o[nt] = Op::mfma1(vh, pl, o[nt]);
         }
-        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[nt], 0, 0, 0);
+        o[nt] = Op::mfma1(vh, ph, o[nt]);
       }
     }
   }

@@ -35,6 +35,18 @@ TAMF_DEV void split_bf16x3(float a, float b, uint32_t& hi, uint32_t& lo) {
   hi = pack_bf16(a, b);
   lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u));
 }
+// the same for IEEE half: hi = f16(v), lo = f16(v - hi) (v - hi is exact in fp32); |v| must stay below 65504
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tamf_f16x2 __attribute__((ext_vector_type(2)));
+TAMF_DEV uint32_t pack_f16(float a, float b) {
+  const tamf_f32x2 f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tamf_f16x2));
+}
+TAMF_DEV void split_f16x3(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_f16(a, b);
+  const tamf_f16x2 h = __builtin_bit_cast(tamf_f16x2, hi);
+  lo = pack_f16(a - (float)h[0], b - (float)h[1]);
+}
 TAMF_DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
 TAMF_DEV int as_i(float v) { return __builtin_bit_cast(int, v); }
 
@@ -93,6 +105,7 @@ struct OpF32 {
   typedef float elem_t;
   static constexpr int EB = 4;     // bytes per logical element inside a row
   static constexpr int PREC = 0;
+  static constexpr bool SPLIT = false;
   static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
     // the 4 floats of a fragment are 4 K-steps of v_mfma_f32_16x16x4_f32 (lane group g supplies k = g); A and B use
     // the same permuted K order, so the products pair up exactly (bitwise a k-ordered fp32 fma chain)
@@ -137,6 +150,11 @@ struct OpBF16 {
   typedef uint16_t elem_t;
   static constexpr int EB = 2;
   static constexpr int PREC = 1;
+  static constexpr bool SPLIT = false;  // one 16-bit plane
+  static TAMF_DEV f32x4 mfma1(const int4& a, const int4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static TAMF_DEV void split2(float a, float b, uint32_t& hi, uint32_t& lo) { hi = pack_bf16(a, b); lo = hi; }
   static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
@@ -157,6 +175,11 @@ struct OpBF16X3 {
   typedef uint16_t elem_t;
   static constexpr int EB = 4;  // hi + lo
   static constexpr int PREC = 2;
+  static constexpr bool SPLIT = true;  // hi and lo planes, 3 MFMAs per product
+  static TAMF_DEV f32x4 mfma1(const int4& a, const int4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static TAMF_DEV void split2(float a, float b, uint32_t& hi, uint32_t& lo) { split_bf16x3(a, b, hi, lo); }
   static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
     const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), al = __builtin_bit_cast(bf16x8, a[1]);
     const bf16x8 bh = __builtin_bit_cast(bf16x8, b[0]), bl = __builtin_bit_cast(bf16x8, b[1]);
@@ -184,6 +207,47 @@ struct OpBF16X3 {
   static TAMF_DEV float load1(const elem_t* base, long idx) {
     const char* p = (const char*)base + byte_off(idx);
     return bf2f(*(const uint16_t*)p) + bf2f(*(const uint16_t*)(p + 64));
+  }
+};
+
+// split-fp16 operands: x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 significand bits, i.e. ~2^-22 relative operand
+// error (fp32 keeps 2^-24; bf16x3 2^-17), three f16 MFMAs per product (lo.hi + hi.lo + hi.hi, the lo.lo term is below
+// 2^-22).  Same 128-byte row groups as bf16x3: [hi: 32 f16 | lo: 32 f16].  Range: |x| <= 65504 (an element beyond it turns
+// into inf / NaN exactly like a non-finite activation would); f16 subnormal lo parts (|x| < ~0.12) keep an absolute
+// error of 3e-8.
+struct OpF16X3 {
+  typedef uint16_t elem_t;
+  static constexpr int EB = 4;
+  static constexpr int PREC = 3;
+  static constexpr bool SPLIT = true;
+  static TAMF_DEV f32x4 mfma1(const int4& a, const int4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static TAMF_DEV void split2(float a, float b, uint32_t& hi, uint32_t& lo) { split_f16x3(a, b, hi, lo); }
+  static TAMF_DEV void mma(f32x4& acc, const int4 (&a)[2], const int4 (&b)[2]) {
+    acc = mfma1(a[1], b[0], acc);
+    acc = mfma1(a[0], b[1], acc);
+    acc = mfma1(a[0], b[0], acc);
+  }
+  static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
+  template <int N>
+  static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
+    uint32_t wh[N / 2], wl[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
+    char* p = (char*)base + byte_off(idx);
+    store_bf16_vec<N>(p, wh);
+    store_bf16_vec<N>(p + 64, wl);
+  }
+  static TAMF_DEV void store1(elem_t* base, long idx, float v) {
+    char* p = (char*)base + byte_off(idx);
+    const _Float16 hi = (_Float16)v;
+    *(_Float16*)p = hi;
+    *(_Float16*)(p + 64) = (_Float16)(v - (float)hi);
+  }
+  static TAMF_DEV float load1(const elem_t* base, long idx) {
+    const char* p = (const char*)base + byte_off(idx);
+    return (float)*(const _Float16*)p + (float)*(const _Float16*)(p + 64);
   }
 };
 

@@ -118,19 +118,6 @@ struct EpiBiasAct {
       OutOp::template store<8>(out, (long)gr * ldo + gn, v);
     }
   }
-  // item API of the pipelined kernel (tamf_gemm_pipe.h): 8 consecutive columns of one row, bias already added
-  TAMF_DEV bool pipe_ok() const { return rowadd == nullptr; }
-  TAMF_DEV const float* pipe_bias() const { return bias; }
-  TAMF_DEV void item8(float (&v)[8], int gr, int gn) const {
-    if (act == ACT_SILU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (OutOp::PREC == 0) ? silu_exact(v[j]) : silu_fast(v[j]);
-    } else if (act == ACT_GELU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (OutOp::PREC == 0) ? gelu_erf(v[j]) : gelu_erf_fast(v[j]);
-    }
-    OutOp::template store<8>(out, (long)gr * ldo + gn, v);
-  }
 };
 
 // in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed

@@ -16,9 +16,17 @@
 
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
-#include "tamf_gemm_pipe.h"
 #include "tamf_geom.h"
 #include "tamf_misc.h"
+
+// run EXPR with `Op` bound to the operand traits of arithmetic mode `prec` (tamf_precision)
+#define TAMF_WITH_OP(prec, EXPR)                                         \
+  switch (prec) {                                                        \
+    case TAMF_PREC_F32: { typedef OpF32 Op; EXPR; } break;               \
+    case TAMF_PREC_BF16: { typedef OpBF16 Op; EXPR; } break;             \
+    case TAMF_PREC_BF16X3: { typedef OpBF16X3 Op; EXPR; } break;         \
+    default: { typedef OpF16X3 Op; EXPR; } break;                        \
+  }
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -166,11 +174,17 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
   for (int r = 0; r < N; ++r)
     for (int k = 0; k < K; ++k) {
       const float v = w[(size_t)r * K + k];
-      const uint16_t hi = h_f2bf(v);
       const size_t idx = (size_t)r * ldk + k;
       const size_t o = (idx >> 5) * 64 + (idx & 31);  // in uint16 units: 64 per 128-byte group
-      h[o] = hi;
-      h[o + 32] = h_f2bf(v - h_bf2f(hi));
+      if (prec == TAMF_PREC_F16X3) {
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        memcpy(&h[o], &hi, 2);
+        memcpy(&h[o + 32], &lo, 2);
+      } else {
+        const uint16_t hi = h_f2bf(v);
+        h[o] = hi;
+        h[o + 32] = h_f2bf(v - h_bf2f(hi));
+      }
     }
   return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * 2);
 }
@@ -178,31 +192,11 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // ------------------------------------------------------------------------------------------------
 // kernel launchers
 // ------------------------------------------------------------------------------------------------
-// GemmArgs::krot bits (tamf_gemm.h): rotation stride, L2 touch-prefetch distance, ablation flags.
-// -1 = per-kernel default: the 64-row LayerNorm tiles prefetch 4 K tiles ahead into L2 (their weight panel is shared by
-// every workgroup and has been evicted from the 4 MB L2 by the other GEMMs of the layer: 186 -> 153 us in situ), the
-// 128 x 128 tiles do not (it costs them 5-8 %).  TAMF_GEMM_KROT / tamf_set_gemm_tuning override both.
-static int g_krot = []() {
-  const char* e = getenv("TAMF_GEMM_KROT");
-  return e ? atoi(e) : -1;
-}();
-// FFN2 (K = ff) as one LayerNorm-fused 64 x d GEMM (0) or as a 128 x 128-tile GEMM + row-wise LayerNorm kernel (1).
-// -1 = default: two kernels in bf16x3 (139 -> 106 + 21 us in situ: the 64 x d tile streams the whole 4 MB split weight
-// panel through every CU), fused otherwise (bf16: 69 vs 52 + 19 us).  TAMF_FFN2_TWO_KERNEL overrides.
-static int g_ffn2_two_kernel = []() {
-  const char* e = getenv("TAMF_FFN2_TWO_KERNEL");
-  return e ? atoi(e) : -1;
-}();
-// TAMF_GEMM_SPLIT: 0 = never split left-over tiles, 2 / 4 = cap the split factor, unset = automatic
-static int g_gemm_split = []() {
-  const char* e = getenv("TAMF_GEMM_SPLIT");
-  return e ? atoi(e) : -1;
-}();
-// TAMF_GEMM_PERSIST: 0 = never use the persistent one-round grid
-static int g_gemm_persist = []() {
-  const char* e = getenv("TAMF_GEMM_PERSIST");
-  return e ? atoi(e) : 1;
-}();
+// GemmArgs::krot bits (tamf_gemm.h): L2 touch-prefetch distance, XCD arrangement.  -1 = per-kernel default: the 64-row
+// LayerNorm tiles prefetch 4 K tiles ahead into L2 (their weight panel is shared by every workgroup and has been evicted
+// from the 4 MB L2 by the other GEMMs of the layer: 186 -> 153 us in situ), the 128 x 128 tiles do not (it costs them
+// 5-8 %).  Only the kernel benchmark hook (tamf_bench_gemm) overrides it.
+static int g_krot = -1;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
 // resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch
@@ -249,9 +243,8 @@ struct GemmLaunch {
       // (a launch of less than one round is sliced as long as the slices fit the workgroup slots: two slices sharing a CU
       // overlap each other's latencies, one whole tile alone on a CU does not)
       const int n_full = (tiles / g_wg_slots) * g_wg_slots, rem = tiles - n_full, cus = n_full ? g_wg_slots / 2 : g_wg_slots;
-      if (g_gemm_split != 0 && rem > 0) {
+      if (rem > 0) {
         split = (rem * 4 <= cus) ? 4 : (rem * 2 <= cus) ? 2 : 1;
-        if (g_gemm_split > 0 && g_gemm_split < split) split = g_gemm_split;
         if (split > 1) gb.n_full = n_full;
       }
     }
@@ -259,7 +252,7 @@ struct GemmLaunch {
     int nblk = gb.n_full + (tiles - gb.n_full) * split;
     // more than one round, a partial last round and no slices: a persistent one-round grid balances the CUs (the hardware
     // hands a freed slot to the next workgroup greedily; QKV's 1248 tiles ended up as 4..6 per CU instead of 4..5)
-    if (g_gemm_persist != 0 && split == 1 && BM == 128 && tiles > g_wg_slots && tiles % g_wg_slots != 0) {
+    if (split == 1 && BM == 128 && tiles > g_wg_slots && tiles % g_wg_slots != 0) {
       gb.n_tiles = tiles;
       nblk = g_wg_slots;
     }
@@ -277,37 +270,8 @@ template <class Epi> struct EpiCanSplit { static constexpr bool value = false; }
 template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool value = true; };
 template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
-// TAMF_GEMM_PIPE: 1 = use the persistent pipelined kernel (tamf_gemm_pipe.h) where it applies
-static int g_gemm_pipe = []() {
-  const char* e = getenv("TAMF_GEMM_PIPE");
-  return e ? atoi(e) : 0;
-}();
-template <class Op, class Epi>
-struct PipeLaunch {
-  static hipError_t prepare() {
-    static int state = 0;  // 0 unknown, 1 ok, -1 unavailable
-    if (state == 0)
-      state = hipFuncSetAttribute((const void*)gemm_pipe_kernel<Op, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_SMEM) == hipSuccess ? 1 : -1;
-    return state == 1 ? hipSuccess : hipErrorInvalidValue;
-  }
-  static bool applies(const GemmArgs<Op>& ga) {
-    return ga.N % PIPE_BN == 0 && (ga.K * Op::EB) % GEMM_BKB == 0 && (ga.K * Op::EB) / GEMM_BKB >= 8 && ((ga.K * Op::EB) / GEMM_BKB) % 2 == 0 && ga.M > 0;
-  }
-  static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
-    const int tiles = (ga.N / PIPE_BN) * ((ga.M + PIPE_BM - 1) / PIPE_BM), cus = g_wg_slots / 2;
-    hipLaunchKernelGGL((gemm_pipe_kernel<Op, Epi>), dim3(tiles < cus ? tiles : cus), dim3(PIPE_NW * 64), PIPE_SMEM, st, ga, epi);
-    return hipGetLastError();
-  }
-};
-template <class Op, class Epi> struct EpiHasPipe { static constexpr bool value = false; };
-template <class Op> struct EpiHasPipe<Op, EpiBiasAct<Op>> { static constexpr bool value = true; };
-
 template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
-  if constexpr (EpiHasPipe<Op, Epi>::value) {
-    if (g_gemm_pipe && epi.rowadd == nullptr && PipeLaunch<Op, Epi>::applies(ga) && PipeLaunch<Op, Epi>::prepare() == hipSuccess)
-      return PipeLaunch<Op, Epi>::launch(ga, epi, st);
-  }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
 template <class Op>
@@ -340,8 +304,7 @@ static hipError_t prepare_all() {
 template <class Op>
 static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
   const int nqt = (aa.Sp + 15) / 16;
-  static const int nw_env = []() { const char* e = getenv("TAMF_ATTN_NW"); return e ? atoi(e) : 0; }();
-  const int nw_max = (nw_env >= 1 && nw_env <= 16) ? nw_env : 16;  // one workgroup per (clip, head) up to 256 queries: K/V streamed once
+  const int nw_max = 16;  // one workgroup per (clip, head) up to 256 queries: K/V streamed once
   const int chunks = (nqt + nw_max - 1) / nw_max;
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
@@ -379,7 +342,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (arch->ff_size <= 0 || arch->ff_size % 128) return fail(nullptr, TAMF_ERR_INVALID, "ff_size must be a multiple of 128");
   if (arch->num_layers <= 0 || arch->num_layers > 64) return fail(nullptr, TAMF_ERR_INVALID, "bad num_layers");
   if (arch->input_dim <= 0 || arch->input_dim > 128) return fail(nullptr, TAMF_ERR_INVALID, "input_dim must be in [1,128]");
-  if (precision < 0 || precision > 2) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   if (arch->kind != TAMF_KIND_G && arch->kind != TAMF_KIND_R) return fail(nullptr, TAMF_ERR_INVALID, "unknown model kind");
   if (max_batch <= 0 || max_frames <= 0 || max_frames > 4990) return fail(nullptr, TAMF_ERR_INVALID, "bad max_batch/max_frames");
   int ndev = 0;
@@ -419,8 +382,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_wg_slots = 2 * cus;
   }
   hipError_t pe = prepare_all<OpF32>();
-  if (pe == hipSuccess && precision == TAMF_PREC_BF16) pe = prepare_all<OpBF16>();
-  if (pe == hipSuccess && precision == TAMF_PREC_BF16X3) pe = prepare_all<OpBF16X3>();
+  if (pe == hipSuccess && precision != TAMF_PREC_F32) TAMF_WITH_OP(precision, pe = prepare_all<Op>());
   if (pe != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, std::string("kernel attribute setup failed: ") + hipGetErrorString(pe)));
   if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess)
@@ -788,7 +750,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      if ((g_ffn2_two_kernel < 0 ? Op::PREC == 2 : g_ffn2_two_kernel != 0) && ctx->tmp32) {
+      if (Op::SPLIT && ctx->tmp32) {
         // 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
@@ -857,11 +819,8 @@ extern "C" int tamf_denoise(tamf_ctx* ctx, const float* x_dev, const int64_t* t_
   if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "tamf_denoise needs a G context");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  switch (ctx->prec) {
-    case TAMF_PREC_F32: return denoise_impl<OpF32>(ctx, x_dev, t_dev, x0_out_dev, st);
-    case TAMF_PREC_BF16: return denoise_impl<OpBF16>(ctx, x_dev, t_dev, x0_out_dev, st);
-    default: return denoise_impl<OpBF16X3>(ctx, x_dev, t_dev, x0_out_dev, st);
-  }
+  TAMF_WITH_OP(ctx->prec, return denoise_impl<Op>(ctx, x_dev, t_dev, x0_out_dev, st));
+  return 0;
 }
 
 template <class Op>
@@ -885,11 +844,8 @@ extern "C" int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, con
   if (ctx->arch.kind != TAMF_KIND_R) return fail(ctx, TAMF_ERR_STATE, "tamf_refine needs an R context");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  switch (ctx->prec) {
-    case TAMF_PREC_F32: return refine_impl<OpF32>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
-    case TAMF_PREC_BF16: return refine_impl<OpBF16>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
-    default: return refine_impl<OpBF16X3>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st);
-  }
+  TAMF_WITH_OP(ctx->prec, return refine_impl<Op>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st));
+  return 0;
 }
 
 extern "C" int tamf_ddpm_step(tamf_ctx* ctx, const float* x_t_dev, const float* x0_dev, int32_t t, const float* noise_dev,
@@ -956,11 +912,8 @@ extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t 
   if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "tamf_sample_loop needs a G context");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  switch (ctx->prec) {
-    case TAMF_PREC_F32: return loop_impl<OpF32>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
-    case TAMF_PREC_BF16: return loop_impl<OpBF16>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
-    default: return loop_impl<OpBF16X3>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st);
-  }
+  TAMF_WITH_OP(ctx->prec, return loop_impl<Op>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st));
+  return 0;
 }
 
 extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
@@ -993,11 +946,7 @@ extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, d
   hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B);
   for (hipEvent_t& e : cal) (void)hipEventRecord(e, st);
   (void)hipEventRecord(ev0, st);
-  switch (ctx->prec) {
-    case TAMF_PREC_F32: rc = profile_impl<OpF32>(ctx, st); break;
-    case TAMF_PREC_BF16: rc = profile_impl<OpBF16>(ctx, st); break;
-    default: rc = profile_impl<OpBF16X3>(ctx, st); break;
-  }
+  TAMF_WITH_OP(ctx->prec, rc = profile_impl<Op>(ctx, st));
   ctx->prof_on = false;
   hipError_t se = hipStreamSynchronize(st);
   int n = 0;
@@ -1078,12 +1027,9 @@ extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K
                               const float* bias_dev, int32_t act, float* c_dev, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || N % 128) return fail(nullptr, TAMF_ERR_INVALID, "N must be a multiple of 128");
   hipStream_t st = (hipStream_t)stream;
-  switch (precision) {
-    case TAMF_PREC_F32: return test_gemm_impl<OpF32>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
-    case TAMF_PREC_BF16: return test_gemm_impl<OpBF16>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
-    case TAMF_PREC_BF16X3: return test_gemm_impl<OpBF16X3>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st);
-    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
-  }
+  if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  TAMF_WITH_OP(precision, return test_gemm_impl<Op>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st));
+  return 0;
 }
 
 extern "C" int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
@@ -1091,12 +1037,9 @@ extern "C" int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_
                                  const float* beta_dev, float* y_dev, void* stream) {
   if (M <= 0 || K <= 0 || !(N == 128 || N == 256 || N == 512)) return fail(nullptr, TAMF_ERR_INVALID, "N must be 128/256/512");
   hipStream_t st = (hipStream_t)stream;
-  switch (precision) {
-    case TAMF_PREC_F32: return test_gemm_impl<OpF32>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
-    case TAMF_PREC_BF16: return test_gemm_impl<OpBF16>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
-    case TAMF_PREC_BF16X3: return test_gemm_impl<OpBF16X3>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st);
-    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
-  }
+  if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  TAMF_WITH_OP(precision, return test_gemm_impl<Op>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st));
+  return 0;
 }
 
 template <class Op>
@@ -1131,12 +1074,9 @@ extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int3
                                    float* out_dev, void* stream) {
   if (B <= 0 || S <= 0 || H <= 0 || !(hd == 64 || hd == 128)) return fail(nullptr, TAMF_ERR_INVALID, "bad attention shape");
   hipStream_t st = (hipStream_t)stream;
-  switch (precision) {
-    case TAMF_PREC_F32: return test_attn_impl<OpF32>(B, S, H, hd, qkv_dev, out_dev, st);
-    case TAMF_PREC_BF16: return test_attn_impl<OpBF16>(B, S, H, hd, qkv_dev, out_dev, st);
-    case TAMF_PREC_BF16X3: return test_attn_impl<OpBF16X3>(B, S, H, hd, qkv_dev, out_dev, st);
-    default: return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
-  }
+  if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  TAMF_WITH_OP(precision, return test_attn_impl<Op>(B, S, H, hd, qkv_dev, out_dev, st));
+  return 0;
 }
 
 // random operand fill for the kernel benchmarks (values in [-1, 1))
@@ -1188,8 +1128,7 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
       e = gemm128<Op>(ga, ep, st);
     } else {
-      static const int bench_act = []() { const char* e = getenv("TAMF_BENCH_ACT"); return e ? atoi(e) : (int)ACT_GELU; }();
-      EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, bench_act};
+      EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
       e = gemm128<Op>(ga, ep, st);
     }
   }
@@ -1212,13 +1151,9 @@ extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot
   const int saved_rot = g_krot;
   g_krot = krot;  // -1 = per-kernel default; >= 0 = GemmArgs::krot bits (tamf_gemm.h)
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  switch (precision) {
-    case TAMF_PREC_F32: rc = bench_gemm_impl<OpF32>(epi_kind, M, N, K, iters, ms_out, st); break;
-    case TAMF_PREC_BF16: rc = bench_gemm_impl<OpBF16>(epi_kind, M, N, K, iters, ms_out, st); break;
-    case TAMF_PREC_BF16X3: rc = bench_gemm_impl<OpBF16X3>(epi_kind, M, N, K, iters, ms_out, st); break;
-    default: rc = fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
-  }
+  int rc = 0;
+  if (precision < 0 || precision > TAMF_PREC_F16X3) rc = fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  else TAMF_WITH_OP(precision, rc = bench_gemm_impl<Op>(epi_kind, M, N, K, iters, ms_out, st));
   g_krot = saved_rot;
   return rc;
 }

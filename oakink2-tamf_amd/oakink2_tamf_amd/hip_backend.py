@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x3": 3}
 KINDS = {"G": 0, "R": 1}
 
 

@@ -54,7 +54,7 @@ def parse_args(argv: List[str]):
     ap.add_argument("--exp_id", default="main")
     ap.add_argument("--commit", action="store_true", help="write outputs (dry run otherwise)")
     ap.add_argument("--synthetic", default=None, help="B,T : synthetic conditioning for B clips of T frames")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--diffusion_steps", type=int, default=1000)
     known, rest = ap.parse_known_args(argv)

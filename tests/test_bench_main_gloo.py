@@ -1,0 +1,54 @@
+"""CPU, world_size 2 (gloo): bench.py's own multi-rank path - self-spawned ranks, process-group set-up, per-rank clip
+ranges, the result gather inside the timed region, max-over-ranks timing and the single JSON line - driven through
+`python bench.py --gpus 2` exactly as on a GPU node, with the HIP sampler replaced by tests/bench_stub.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if env_extra:
+        env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--sampler", "bench_stub:StubSampler",
+           "--arch", "arch_mdm", "--batch", "3", "--frames", "8", "--ddpm-steps", "4", "--steps", "2", "--warmup", "1"] + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_self_spawns_two_ranks_and_gathers():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["world_size_seen"] == 2
+    assert j["config"]["rank_clip_ranges"] == [[0, 3], [3, 6]]
+    assert j["config"]["global_clips"] == 6 and j["finite"] is True
+    assert j["value"] > 0 and abs(j["value"] - 6 * 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+
+
+def test_bench_under_an_external_launcher_env():
+    """RANK / WORLD_SIZE / MASTER_* from the environment (the torch.distributed.run contract), world size 1."""
+    r = _run(["--gpus", "1"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["rank_clip_ranges"] == [[0, 3]]
+
+
+def test_bench_presets():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = bench.parse_args(["--config", "3"])
+    assert a.batch == 32 and a.dtype == bench.DEFAULT_DTYPE
+    a = bench.parse_args(["--config", "5"])
+    assert a.batch == 64 and a.dtype == "bf16"
+    a = bench.parse_args([])
+    assert a.batch == 64 and a.frames == 196 and a.ddpm_steps == 1000 and a.gpus == 1
+    assert bench.flops_per_clip_step(bench.ARCHS["arch_mdm_l"], 196) == 11127660544  # 11.128 GF per clip-step

@@ -1,10 +1,11 @@
 """GPU: the HIP denoiser / DDPM loop through the C-ABI against the golden vectors captured from the reference
 and against the oracle on the same inputs.
 
-Stated fp32 tolerances (max abs, outputs are O(1)):
-  f32    : forward 2e-5, loops 5e-5          (exact-fp32 MFMA; only summation order differs from torch-CPU)
-  bf16x3 : forward 5e-4, loops 1e-3          (split-bf16 operands, fp32 accumulate)
-  bf16   : forward 6e-2 (reported, bf16 operands); loops 1e-1
+Gates (max abs, outputs are O(1)) = about 3x the error observed on MI355X:
+  f32    : forward 1e-5, loops 1e-5          (exact-fp32 MFMA; only summation order differs from torch-CPU)
+  f16x3  : forward 1e-5, loops 1e-5          (split-fp16 operands, 22 significand bits, fp32 accumulate)
+  bf16x3 : forward 6e-5, loops 6e-5          (split-bf16 operands, 16 significand bits)
+  bf16   : forward 3e-2, loops 3e-2          (bf16 operands; reported, BASELINE config 5)
 """
 import numpy as np
 import pytest
@@ -14,8 +15,9 @@ from conftest import golden_cond, load_golden
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = {"f32": 2e-5, "bf16x3": 5e-4, "bf16": 6e-2}
-LOOP_TOL = {"f32": 5e-5, "bf16x3": 1e-3, "bf16": 1e-1}
+FWD_TOL = {"f32": 1e-5, "f16x3": 1e-5, "bf16x3": 6e-5, "bf16": 3e-2}
+LOOP_TOL = {"f32": 1e-5, "f16x3": 1e-5, "bf16x3": 6e-5, "bf16": 3e-2}
+PRECS = list(FWD_TOL)
 
 
 def _arch_dict(a):
@@ -42,7 +44,7 @@ def _set_cond(ctx, cond):
 FWD_CASES = ["tiny", "tiny_ragged", "tiny_nonfinite", "arch_mdm", "arch_mdm_l", "arch_mdm_l_t196"]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", FWD_CASES)
 def test_forward_golden(name, prec):
     from oracle import mdm_oracle as O
@@ -67,7 +69,7 @@ def test_forward_golden(name, prec):
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_loop_tiny_10_every_step(prec, use_graph):
     from oracle import mdm_oracle as O
@@ -88,7 +90,7 @@ def test_loop_tiny_10_every_step(prec, use_graph):
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", PRECS)
 def test_loop_config0_arch_mdm_b4_t64_50(prec):
     """BASELINE.json configs[0] on the GPU path: arch_mdm, B=4, T=64, 50 steps, noise in reference call order."""
     from oracle import det
@@ -109,7 +111,7 @@ def test_loop_config0_arch_mdm_b4_t64_50(prec):
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 def test_loop_tiny_1000(prec):
     from oracle import det
     from oracle import mdm_oracle as O

@@ -1,0 +1,175 @@
+"""GPU: parity at the BENCHMARKED shapes (BASELINE.json configs[1], [3] shard, [4]) - the tile-scheduling branches the
+bench runs (persistent one-round grids, remainder slices, XCD tile arrangements, fused FFN row tiles) are only reached
+at M = B * Sp = 13 312 rows, so they get their own oracle comparison here.
+
+  (i)   arch_mdm_l, B = 64, T = 196: one denoiser evaluation on all 64 clips against oracle.denoiser_forward
+  (ii)  the same shape, a complete 5-step supplied-noise DDPM loop against oracle.sample_loop
+  (iii) the GEMM hooks at (13312, 2048, 512), (13312, 1536, 512), (13312, 512, 2048), (13312, 512, 512) against float64
+  (iv)  clip i sampled inside the B = 64 batch is bit-identical to clip i sampled alone
+  (v)   B = 32 and B = 48 (other tile remainders; config 3's per-GPU shard)
+  (vi)  arch_refine, B = 64, T = 196 against oracle.refine_forward (config 4)
+
+Tolerances: about 3x the error observed on MI355X (max abs, outputs are O(1)); see DESIGN.md section 2.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_hip_forward import FWD_TOL, LOOP_TOL, _make_ctx, _set_cond  # noqa: E402
+
+PRECS = list(FWD_TOL)
+B_FULL, T_FULL = 64, 196
+
+
+def _sub(cond, sl):
+    return {k: (v[sl] if isinstance(v, torch.Tensor) else list(v[sl])) for k, v in cond.items()}
+
+
+@pytest.fixture(scope="module")
+def full():
+    """weights, conditioning, input and the oracle's outputs for the bench shape (computed once: ~5 s per forward)"""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    cond = O.det_cond(B_FULL, T_FULL, tag="full/c", arch=arch)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B_FULL, 99, 1, T_FULL, generator=g)
+    t = torch.full((B_FULL,), 500, dtype=torch.long)
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd, arch, x, t, cond)
+    return dict(arch=arch, sd=sd, cond=cond, x=x, t=t, ref=ref)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_forward_b64_t196_vs_oracle(full, prec):
+    ctx = _make_ctx(full["arch"], full["sd"], B_FULL, T_FULL, prec)
+    _set_cond(ctx, full["cond"])
+    out = ctx.denoise(full["x"], full["t"]).cpu()
+    assert torch.isfinite(out).all()
+    per_clip = (out - full["ref"]).abs().amax(dim=(1, 2, 3))
+    err = float(per_clip.max())
+    print(f"fullsize forward[{prec}] B=64 T=196: max|err| = {err:.3e} (worst clip {int(per_clip.argmax())})")
+    assert err < FWD_TOL[prec], (prec, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B", [32, 48])
+def test_forward_other_batch_sizes(full, prec, B):
+    """B = 32 is config 3's per-GPU shard, B = 48 a batch that is not a multiple of the row-tile grouping; clips are
+    independent, so the reference is the first B clips of the B = 64 evaluation."""
+    ctx = _make_ctx(full["arch"], full["sd"], B, T_FULL, prec)
+    _set_cond(ctx, _sub(full["cond"], slice(0, B)))
+    out = ctx.denoise(full["x"][:B], full["t"][:B]).cpu()
+    err = float((out - full["ref"][:B]).abs().max())
+    print(f"fullsize forward[{prec}] B={B}: max|err| = {err:.3e}")
+    assert err < FWD_TOL[prec], (prec, B, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_loop5_b64_t196_vs_oracle(full, prec):
+    from oracle import det
+    from oracle import mdm_oracle as O
+
+    N = 5
+    tab = O.make_tables(N, "cosine")
+    shape = (B_FULL, 99, 1, T_FULL)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag("full/eps", k), shape) for k in range(N + 1)]))
+    with torch.no_grad():
+        ref = O.sample_loop(full["sd"], full["arch"], tab, full["cond"], shape, lambda k: draws[k])
+    ctx = _make_ctx(full["arch"], full["sd"], B_FULL, T_FULL, prec, n_steps=N)
+    _set_cond(ctx, full["cond"])
+    out = ctx.sample_loop(noise=draws).cpu()
+    err = float((out - ref).abs().max())
+    print(f"fullsize 5-step loop[{prec}]: max|err| = {err:.3e}")
+    assert err < LOOP_TOL[prec], (prec, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", [p for p in PRECS if p != "bf16"])
+def test_clip_in_b64_equals_clip_alone(full, prec):
+    """Sharding invariance at the bench shape: a clip's Philox-noise sample does not depend on the batch around it."""
+    N = 3
+    ctx = _make_ctx(full["arch"], full["sd"], B_FULL, T_FULL, prec, n_steps=N)
+    _set_cond(ctx, full["cond"])
+    whole = ctx.sample_loop(noise=None, seed=7, clip_id_base=1000).cpu()
+    for i in (0, 37, 63):
+        _set_cond(ctx, _sub(full["cond"], slice(i, i + 1)))
+        one = ctx.sample_loop(noise=None, seed=7, clip_id_base=1000 + i).cpu()
+        assert torch.equal(one[0], whole[i]), (prec, i, float((one[0] - whole[i]).abs().max()))
+    _set_cond(ctx, _sub(full["cond"], slice(32, 64)))
+    half = ctx.sample_loop(noise=None, seed=7, clip_id_base=1032).cpu()
+    assert torch.equal(half, whole[32:])
+    ctx.close()
+
+
+GEMM_TOL = {"f32": 1e-5, "f16x3": 2e-5, "bf16x3": 1e-4, "bf16": 2e-2}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("N,K", [(2048, 512), (1536, 512), (512, 2048), (512, 512)])
+def test_gemm_bench_shapes(prec, N, K):
+    """The launcher branches of M = 13 312: persistent one-round grid (1 248 QKV tiles), full rounds + slices (FFN1),
+    the XCD tile arrangements."""
+    from oakink2_tamf_amd import hip_backend as hb
+
+    M = 13312
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), 0).double().cpu()
+    ref = a.double() @ w.double().t() + b.double()
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    assert rel < GEMM_TOL[prec], (prec, N, K, rel)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("K", [512, 2048])
+def test_gemm_ln_bench_shapes(prec, K):
+    from oakink2_tamf_amd import hip_backend as hb
+
+    M, N = 13312, 512
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    ga = 1 + 0.1 * torch.randn(N, generator=g)
+    be = 0.1 * torch.randn(N, generator=g)
+    v = (a.double() @ w.double().t() + b.double()) + r.double()
+    ref = torch.nn.functional.layer_norm(v, (N,), ga.double(), be.double(), 1e-5)
+    got = hb.test_gemm_ln(prec, a.cuda(), w.cuda(), b.cuda(), r.cuda(), ga.cuda(), be.cuda()).double().cpu()
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    assert rel < GEMM_TOL[prec], (prec, K, rel)
+
+
+REFINE_TOL = {"f32": 3e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 1e-1}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_refine_b64_t196_vs_oracle(prec):
+    """BASELINE.json configs[3]: the R trunk at B = 64, T = 196 (synthetic h2o_dist) against oracle.refine_forward."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_REFINE
+    sd = O.det_state_dict(arch, tag="fullr/w")
+    cond = O.det_cond(B_FULL, T_FULL, tag="fullr/c", arch=arch)
+    g = torch.Generator().manual_seed(3)
+    x_in = torch.randn(B_FULL, T_FULL, 99, generator=g)
+    h2o = torch.rand(B_FULL, T_FULL, 778, generator=g) * 0.2
+    with torch.no_grad():
+        ref = O.refine_forward(sd, arch, x_in, h2o, cond)
+    ctx = _make_ctx(arch, sd, B_FULL, T_FULL, prec)
+    _set_cond(ctx, cond)
+    out = ctx.refine(x_in, h2o).cpu()
+    err = float((out - ref).abs().max())
+    print(f"fullsize refine[{prec}]: max|err| = {err:.3e}")
+    assert err < REFINE_TOL[prec], (prec, err)
+    ctx.close()
