@@ -76,6 +76,16 @@ TAMF_DEV float erf_as(float x) {
 }
 TAMF_DEV float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
+// Per-loop inputs of the fused DDPM update.  They live in device memory and are read by the kernel, so the captured graph
+// does not depend on them: a new seed / clip range / noise tensor replays the same executable graph.
+struct LoopParams {
+  const float* noise;   // (n_steps+1, B, F, 1, T) draws in reference call order, or null -> Philox
+  float* dump;          // (n_steps, B, F, 1, T) or null
+  long noise_draw_stride;
+  unsigned long long seed;
+  long long clip_base;
+};
+
 // ---------------------------------------------------------------------------------------------
 // LDS swizzles: a tile row of ROWB bytes is a sequence of 16-byte chunks; an MFMA fragment read takes, for
 // lane (r = lane & 15, g = lane >> 4), chunk 4*kc + g of row r.  XOR-ing the chunk index with a function of

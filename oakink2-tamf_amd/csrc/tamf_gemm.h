@@ -323,11 +323,7 @@ struct EpiHead {
   const float* c2;
   const float* sigma;
   int n_steps;
-  const float* noise;   // (n_steps+1, B, F, 1, T) or null -> Philox
-  long noise_draw_stride;
-  unsigned long long seed;
-  long long clip_base;
-  float* dump;          // (n_steps, B, F, 1, T) or null
+  const LoopParams* __restrict__ lp;  // HEAD_DDPM only
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -359,6 +355,11 @@ struct EpiHead {
       } else {
         const int ti = tcur[0];
         const float k1 = c1[ti], k2 = c2[ti], sg = sigma[ti];
+        const float* noise = lp->noise;
+        float* dump = lp->dump;
+        const long noise_draw_stride = lp->noise_draw_stride;
+        const unsigned long long seed = lp->seed;
+        const long long clip_base = lp->clip_base;
         const unsigned draw = (unsigned)(n_steps - ti);
         const long srow = ((long)b * T + tau) * XK;
         float xt[8], xn[8], ez[8];

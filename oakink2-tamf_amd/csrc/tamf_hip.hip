@@ -43,15 +43,12 @@ struct LayerW {
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
 
+// What a captured step sequence depends on.  Seed, clip range, noise / dump tensors are NOT part of it: the kernels read
+// them from the device-side LoopParams block, so one executable graph serves every loop of the same shape.
 struct GraphKey {
-  int B = -1, T = -1, n_steps = -1;
-  const void* noise = nullptr;
-  void* dump = nullptr;
-  uint64_t seed = 0;
-  int64_t clip_base = 0;
+  int B = -1, T = -1, n_steps = -1, steps_per_graph = 0;
   bool operator==(const GraphKey& o) const {
-    return B == o.B && T == o.T && n_steps == o.n_steps && noise == o.noise && dump == o.dump && seed == o.seed &&
-           clip_base == o.clip_base;
+    return B == o.B && T == o.T && n_steps == o.n_steps && steps_per_graph == o.steps_per_graph;
   }
 };
 
@@ -96,6 +93,10 @@ struct tamf_ctx {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   GraphKey graph_key;
+  hipEvent_t graph_done = nullptr;  // recorded after the last launch of graph_exec: waited for before it is destroyed
+  bool graph_in_flight = false;
+  LoopParams* loop_params = nullptr;
+  int sched_cap = 0;  // allocated length of c1 / c2 / sigma
   int step_kernels = 0;
   // per-launch profiling (tamf_step_profile)
   bool prof_on = false;
@@ -214,15 +215,17 @@ struct GemmLaunch {
     return hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, WGN, Epi, SPLIT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
-  static hipError_t prepare() {
-    static bool done = false;
-    if (done) return hipSuccess;
+  static hipError_t prepare() {  // kernel attributes are per device
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
     hipError_t e = prepare1<1>();
     if constexpr (CAN_SPLIT) {
       if (e == hipSuccess) e = prepare1<2>();
       if (e == hipSuccess) e = prepare1<4>();
     }
-    if (e == hipSuccess) done = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
   }
   static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
@@ -352,6 +355,13 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
                                            "): libtamf_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(nullptr, TAMF_ERR_INVALID, "device index out of range");
 
+  {
+    // the kernels address operands with 32-bit byte offsets and int element indices: refuse shapes beyond them
+    const long long sp = (max_frames + 5 + 7) / 8 * 8, mmax = (long long)max_batch * sp;
+    const long long widest = std::max<long long>(arch->ff_size, 3LL * d);
+    if (mmax * widest * 4 >= (1LL << 32) || (long long)max_batch * max_frames * 896 * 4 >= (1LL << 32))
+      return fail(nullptr, TAMF_ERR_INVALID, "max_batch x max_frames too large for one context (32-bit operand offsets): split the batch");
+  }
   tamf_ctx* ctx = new tamf_ctx();
   ctx->arch = *arch;
   ctx->prec = precision;
@@ -413,7 +423,10 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
   A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
+  A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
   if (rc) return bail(rc);
+  if (hipEventCreateWithFlags(&ctx->graph_done, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(ctx, TAMF_ERR_HIP, "hipEventCreate failed"));
   *out = ctx;
   return 0;
 }
@@ -422,6 +435,7 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  if (ctx->graph_done) (void)hipEventDestroy(ctx->graph_done);
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
@@ -601,6 +615,18 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   return 0;
 }
 
+// destroy the executable graph once its last replay has finished (its launches may still be queued on the caller's stream)
+static int retire_graph(tamf_ctx* ctx) {
+  if (ctx->graph_in_flight) {
+    HIPCHK(ctx, hipEventSynchronize(ctx->graph_done));
+    ctx->graph_in_flight = false;
+  }
+  if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+  if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+  ctx->graph_key = GraphKey();
+  return 0;
+}
+
 extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c1, const double* c2, const double* logvar) {
   if (!ctx || !c1 || !c2 || !logvar || n_steps <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -613,10 +639,19 @@ extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c
     ctx->h_sigma[i] = expf(0.5f * (float)logvar[i]);  // th.exp(0.5 * log_variance) on float32 (:459)
   }
   ctx->n_steps = n_steps;
-  TRY(dev_upload(ctx, &ctx->c1, ctx->h_c1.data(), n_steps));
-  TRY(dev_upload(ctx, &ctx->c2, ctx->h_c2.data(), n_steps));
-  TRY(dev_upload(ctx, &ctx->sigma, ctx->h_sigma.data(), n_steps));
-  ctx->graph_key = GraphKey();
+  if (n_steps > ctx->sched_cap) {  // (re)allocated only when a longer schedule arrives; a captured graph holds these pointers
+    TRY(retire_graph(ctx));
+    const int cap = std::max(n_steps, 1000);
+    TRY(dev_alloc(ctx, (void**)&ctx->c1, (size_t)cap * 4));
+    TRY(dev_alloc(ctx, (void**)&ctx->c2, (size_t)cap * 4));
+    TRY(dev_alloc(ctx, (void**)&ctx->sigma, (size_t)cap * 4));
+    ctx->sched_cap = cap;
+  }
+  // plain (synchronous) copies: ordered after earlier work on the null stream semantics of hipMemcpy
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpy(ctx->c1, ctx->h_c1.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->c2, ctx->h_c2.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->sigma, ctx->h_sigma.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -643,7 +678,6 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
   ctx->Skp = round_up(ctx->S, 32);
   ctx->M = B * ctx->Sp;
   ctx->cond_set = false;
-  ctx->graph_key = GraphKey();
   int j = 0;
   if (ht) {
     hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, text_emb_dev, ctx->Wtxt, ctx->btxt,
@@ -795,7 +829,7 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.c2 = ctx->c2;
   h.sigma = ctx->sigma;
   h.n_steps = ctx->n_steps;
-  h.noise_draw_stride = (long)ctx->B * ctx->F * ctx->T;
+  h.lp = ctx->loop_params;
   return h;
 }
 
@@ -805,7 +839,7 @@ static int denoise_impl(tamf_ctx* ctx, const float* x, const int64_t* t_dev, flo
   const int B = ctx->B, T = ctx->T;
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x, ctx->xs, (E*)ctx->xs_op.p,
                      B, ctx->F, T, ctx->XK, 0, 0ull, 0ll);
-  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)t_dev, 0, B);
+  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)t_dev, 0, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_X0);
   h.x0_out = out;
   TRY(enqueue_step<Op>(ctx, st, h));
@@ -870,33 +904,41 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, noise, ctx->xs,
                      (E*)ctx->xs_op.p, B, ctx->F, T, ctx->XK, noise ? 0 : 1, (unsigned long long)seed,
                      (long long)clip_base);
-  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B);
+  hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
-  h.noise = noise;
-  h.seed = seed;
-  h.clip_base = clip_base;
-  h.dump = dump;
+  hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
+                     (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {
     for (int i = 0; i < N; ++i) {
       TRY(enqueue_step<Op>(ctx, st, h));
       hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B);
     }
   } else {
+    // G consecutive steps per graph (the largest divisor of N up to 16: 10 for N = 1000 -> 100 graph launches per loop);
+    // the sequence is step-agnostic (device-side step counter) and seed-agnostic (LoopParams), so it is captured once per
+    // (B, T, N) and replayed by every later loop
+    int G = 1;
+    for (int g = 2; g <= 16; ++g)
+      if (N % g == 0) G = g;
     GraphKey key;
-    key.B = B; key.T = T; key.n_steps = N; key.noise = noise; key.dump = dump; key.seed = seed; key.clip_base = clip_base;
+    key.B = B; key.T = T; key.n_steps = N; key.steps_per_graph = G;
     if (!(key == ctx->graph_key) || !ctx->graph_exec) {
-      if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
-      if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+      TRY(retire_graph(ctx));
       HIPCHK(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
-      int rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
-      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, ctx->cap_stream, ctx->tcur, B);
+      int rc = 0;
+      for (int g = 0; g < G && rc == 0; ++g) {
+        rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
+        hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, ctx->cap_stream, ctx->tcur, B);
+      }
       hipError_t ee = hipStreamEndCapture(ctx->cap_stream, &ctx->graph);
       if (rc) return rc;
       HIPCHK(ctx, ee);
       HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
       ctx->graph_key = key;
     }
-    for (int i = 0; i < N; ++i) HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+    for (int i = 0; i < N / G; ++i) HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+    HIPCHK(ctx, hipEventRecord(ctx->graph_done, st));
+    ctx->graph_in_flight = true;
   }
   hipLaunchKernelGGL(state_out_kernel, grid1d((long)B * ctx->F * T), dim3(256), 0, st, ctx->xs, out, B, ctx->F, T, ctx->XK);
   HIPCHK(ctx, hipGetLastError());
@@ -921,7 +963,8 @@ extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->s
 template <class Op>
 static int profile_impl(tamf_ctx* ctx, hipStream_t st) {
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
-  h.seed = 1;
+  hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, (const float*)nullptr, (float*)nullptr,
+                     (long)ctx->B * ctx->F * ctx->T, 1ull, 0ll);
   return enqueue_step<Op>(ctx, st, h);
 }
 
@@ -943,7 +986,7 @@ extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, d
   for (hipEvent_t& e : cal) HIPCHK(ctx, hipEventCreate(&e));
   ctx->prof_on = true;
   int rc;
-  hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B);
+  hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B, ctx->n_t > 0 ? ctx->n_t : 1);
   for (hipEvent_t& e : cal) (void)hipEventRecord(e, st);
   (void)hipEventRecord(ev0, st);
   TAMF_WITH_OP(ctx->prec, rc = profile_impl<Op>(ctx, st));

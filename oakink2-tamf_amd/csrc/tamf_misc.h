@@ -132,9 +132,24 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
   Op::template store<VPL>(xop, (long)row * D + c0, v);
 }
 
-__global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B) {
+// current timestep of every clip; clamped to the rows of the timestep-embedding table (the host wrapper raises on an
+// out-of-range t like the reference's pe[timesteps] does - the clamp only keeps an unchecked caller in bounds)
+__global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B, int n_t) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tcur[i] = t_dev ? (int)t_dev[i] : uniform_t;
+  if (i >= B) return;
+  long long t = t_dev ? t_dev[i] : (long long)uniform_t;
+  t = t < 0 ? 0 : (t >= n_t ? n_t - 1 : t);
+  tcur[i] = (int)t;
+}
+__global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float* dump, long stride, unsigned long long seed,
+                                       long long clip_base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    lp->noise = noise;
+    lp->dump = dump;
+    lp->noise_draw_stride = stride;
+    lp->seed = seed;
+    lp->clip_base = clip_base;
+  }
 }
 __global__ void advance_t_kernel(int* tcur, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -64,6 +64,25 @@ def lib() -> ctypes.CDLL:
     return L
 
 
+def hand_side_code(hs) -> int:
+    """'rh' -> 0, 'lh' -> 1 in any of the encodings a batch may carry: the reference's strings (also as bytes or numpy
+    str_ from an .npz), or the 0 / 1 flags of the synthetic conditioning.  Anything else raises ValueError exactly as
+    HandsideProcess does (interaction_segment_mdm.py:284)."""
+    if isinstance(hs, bytes):
+        hs = hs.decode()
+    if isinstance(hs, str):
+        if hs in ("rh", "lh"):
+            return 0 if hs == "rh" else 1
+        raise ValueError(f"unexpected hand_side: {hs}")
+    try:
+        v = int(hs)
+    except (TypeError, ValueError):
+        raise ValueError(f"unexpected hand_side: {hs}") from None
+    if v in (0, 1):
+        return v
+    raise ValueError(f"unexpected hand_side: {hs}")
+
+
 def _stream_ptr(device: torch.device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
@@ -116,6 +135,7 @@ class TamfContext:
         self._h = c_void_p()
         self.B = self.T = 0
         self.n_steps = 0
+        self.max_timesteps = 0
         self._keep = []
         with torch.cuda.device(self.device):
             _check(lib().tamf_ctx_create(ctypes.byref(a), max_batch, max_frames, PRECISIONS[precision],
@@ -133,8 +153,11 @@ class TamfContext:
             pass
 
     # -- weights ------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Mapping[str, torch.Tensor], max_timesteps: int = 1000):
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], max_timesteps: int = 5000):
+        """max_timesteps = rows of the timestep-embedding table; the default covers every t the reference's
+        `pe[timesteps]` lookup accepts (sequence_pos_encoder.pe has 5000 rows)."""
         L = lib()
+        self.max_timesteps = int(max_timesteps)
         for name, t in sd.items():
             if not isinstance(t, torch.Tensor) or name.startswith("clip_model."):
                 continue
@@ -156,14 +179,7 @@ class TamfContext:
     # -- conditioning -------------------------------------------------------------------------
     def set_cond(self, text_embedding: Optional[torch.Tensor], hand_side: Sequence, shape: torch.Tensor,
                  obj_embedding: torch.Tensor, obj_traj: torch.Tensor):
-        side = []
-        for hs in hand_side:
-            if hs == "rh" or (not isinstance(hs, str) and int(hs) == 0):
-                side.append(0)
-            elif hs == "lh" or (not isinstance(hs, str) and int(hs) == 1):
-                side.append(1)
-            else:
-                raise ValueError(f"unexpected hand_side: {hs}")
+        side = [hand_side_code(hs) for hs in hand_side]
         B, nobj, T, _ = obj_traj.shape
         dev = self.device
         te = _dev_f32(text_embedding, dev) if text_embedding is not None else None
@@ -189,6 +205,12 @@ class TamfContext:
         xd = _dev_f32(x, dev)
         assert tuple(xd.shape) == (self.B, self.input_dim, 1, self.T), (tuple(xd.shape), self.B, self.T)
         td = t.detach().to(device=dev, dtype=torch.int64).contiguous()
+        assert td.shape == (self.B,), (tuple(td.shape), self.B)
+        # the reference indexes pe[timesteps] and raises on an index outside the table; so does this path (the device
+        # kernel additionally clamps, so an unchecked caller of the C-ABI cannot read out of bounds)
+        lo, hi = int(td.min()), int(td.max())
+        if lo < 0 or hi >= self.max_timesteps:
+            raise IndexError(f"timestep {lo if lo < 0 else hi} outside the timestep-embedding table [0, {self.max_timesteps})")
         out = torch.empty_like(xd)
         with torch.cuda.device(dev):
             _check(lib().tamf_denoise(self._h, c_void_p(xd.data_ptr()), c_void_p(td.data_ptr()), c_void_p(out.data_ptr()),

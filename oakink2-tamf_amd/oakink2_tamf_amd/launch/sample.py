@@ -23,6 +23,7 @@ from typing import Dict, List
 
 import numpy as np
 
+from ..hip_backend import hand_side_code
 from .formats import write_sample_npy
 
 _logger = logging.getLogger("oakink2_tamf_amd.launch.sample")
@@ -148,7 +149,7 @@ def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, co
         b1 = min(b0 + bs, stop)
         batch = {
             "text_embedding": torch.from_numpy(cond["text_embedding"][b0:b1]).to(device),
-            "hand_side": ["rh" if int(v) == 0 else "lh" for v in cond["hand_side"][b0:b1]],
+            "hand_side": ["rh" if hand_side_code(v) == 0 else "lh" for v in cond["hand_side"][b0:b1]],
             "shape": torch.from_numpy(cond["shape"][b0:b1]).to(device),
             "obj_embedding": torch.from_numpy(cond["obj_embedding"][b0:b1]).to(device),
             "obj_traj": torch.from_numpy(cond["obj_traj"][b0:b1]).to(device),

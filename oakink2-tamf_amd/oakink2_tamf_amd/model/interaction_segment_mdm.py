@@ -76,7 +76,7 @@ class _HipDenoiserBase(nn.Module):
         self._ctx_dirty = True
         self._cond_key = None
         self._sched_key = None
-        self._max_timesteps = 1000
+        self._max_timesteps = 5000  # rows of sequence_pos_encoder.pe: every t the reference accepts
 
     # weights changed -> re-upload lazily
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -119,11 +119,15 @@ class _HipDenoiserBase(nn.Module):
         return None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
 
     def _set_cond(self, ctx, batch, text_embedding):
-        key = (id(batch), tuple(batch["hand_side"]), self._tensor_key(text_embedding), self._tensor_key(batch["shape"]),
-               self._tensor_key(batch["obj_embedding"]), self._tensor_key(batch["obj_traj"]))
+        """Step-invariant conditioning is precomputed once per batch: the cache key is object identity + tensor
+        address / shape / version, and the keyed OBJECTS are kept alive next to the key - a freed batch dict or tensor
+        can therefore never be mistaken for a new one that the allocator placed at the same address."""
+        tensors = (text_embedding, batch["shape"], batch["obj_embedding"], batch["obj_traj"])
+        key = (id(batch), tuple(batch["hand_side"])) + tuple(self._tensor_key(t) for t in tensors)
         if key != self._cond_key:
             ctx.set_cond(text_embedding, batch["hand_side"], batch["shape"], batch["obj_embedding"], batch["obj_traj"])
             self._cond_key = key
+            self._cond_refs = (batch,) + tensors
 
     def train(self, mode: bool = True):
         if mode:
@@ -229,7 +233,9 @@ class InterationSegmentMDM(_HipDenoiserBase):
         N = diffusion.num_timesteps
         self._max_timesteps = max(self._max_timesteps, N)
         ctx = self._context(B, T)
-        skey = (id(diffusion), N)
+        # keyed on the coefficient values themselves (a new diffusion object at a recycled id must not hit)
+        skey = (N, diffusion.posterior_mean_coef1.tobytes(), diffusion.posterior_mean_coef2.tobytes(),
+                diffusion.posterior_log_variance_clipped.tobytes())
         if self._sched_key != skey:
             ctx.set_schedule(diffusion.posterior_mean_coef1, diffusion.posterior_mean_coef2,
                              diffusion.posterior_log_variance_clipped)
