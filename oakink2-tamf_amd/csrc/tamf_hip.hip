@@ -16,6 +16,7 @@
 
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
+#include "tamf_gemm_clip.h"
 #include "tamf_geom.h"
 #include "tamf_misc.h"
 
@@ -273,6 +274,42 @@ template <class Epi> struct EpiCanSplit { static constexpr bool value = false; }
 template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool value = true; };
 template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
+
+// Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip.  Used when the clip has 13 MFMA row tiles (193..208 padded
+// rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
+// else runs on the 128 x 128 tiles.
+template <class Op, int NI, int SUBN, class Epi>
+struct ClipLaunch {
+  typedef ClipCfg<13, NI> C;
+  static hipError_t prepare() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, SUBN, Epi>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::BYTES);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    return e;
+  }
+  static bool applies(int n_clips, int Sp, int N, int K) {
+    if (g_krot >= 0 && (g_krot & 0x100000)) return false;  // kernel benchmark hook: force the 128 x 128 tiles (A/B runs)
+    if (Sp > C::MT || Sp <= C::MT - 16 || N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
+    const int KT = (K * Op::EB) / GEMM_BKB;
+    if (KT < 2 || (KT & 1)) return false;
+    const int cus = g_wg_slots / 2, tiles = n_clips * (N / C::BN), rounds = (tiles + cus - 1) / cus;
+    return tiles * 100 >= rounds * cus * 74;  // >= 74 % of the workgroup slots of its rounds are used
+  }
+  static hipError_t launch(const Op*, const typename Op::elem_t* A, int lda, const typename Op::elem_t* W, int ldw, int n_clips,
+                           int Sp, int N, int K, const Epi& epi, hipStream_t st) {
+    hipError_t e = prepare();
+    if (e != hipSuccess) return e;
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN)};
+    const int cus = g_wg_slots / 2;
+    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, SUBN, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
+    return hipGetLastError();
+  }
+};
+
 template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
@@ -297,6 +334,11 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 3, 64, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, 128, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 4, 256, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 3, 64, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -762,7 +804,10 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
       EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
-      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      if (ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(B, Sp, 3 * d, d))
+        HIPCHK(ctx, (ClipLaunch<Op, 3, 64, EpiQKV<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 3 * d, d, ep, st)));
+      else
+        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
@@ -779,15 +824,22 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
-      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      if (ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
+        HIPCHK(ctx, (ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+      else
+        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      if (Op::SPLIT && ctx->tmp32) {
-        // 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
+      const bool clip2 = ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(B, Sp, d, ff);
+      if ((Op::SPLIT || clip2) && ctx->tmp32) {
+        // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
-        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+        if (clip2)
+          HIPCHK(ctx, (ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
+        else
+          HIPCHK(ctx, gemm128<Op>(ga, ep, st));
         mark("gemm_ffn2", BS * 2.0 * dd * ff);
         const int rows_per_blk = 4;
         dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
@@ -1057,7 +1109,16 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
     e = gemm_ln<Op>(ga, ep, st);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
-    e = gemm128<Op>(ga, ep, st);
+    // M = n * 208 rows: the clip-aligned tiles the encoder layers use at T = 196 (same selection as enqueue_step)
+    const int nc = M / 208;
+    if (M % 208 == 0 && N % 192 == 0 && ClipLaunch<Op, 3, 64, EpiStoreF32>::applies(nc, 208, N, Kp))
+      e = ClipLaunch<Op, 3, 64, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
+    else if (M % 208 == 0 && N % 256 == 0 && ClipLaunch<Op, 4, 256, EpiStoreF32>::applies(nc, 208, N, Kp))
+      e = ClipLaunch<Op, 4, 256, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
+    else if (M % 208 == 0 && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(nc, 208, N, Kp))
+      e = ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
+    else
+      e = gemm128<Op>(ga, ep, st);
   }
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
   if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "sync failed");
@@ -1165,14 +1226,23 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       e = gemm_ln<Op>(ga, ep, st);
     } else if (epi_kind == 3) {
       EpiStoreF32 ep{vec, x, N, ACT_NONE};
-      e = gemm128<Op>(ga, ep, st);
+      if (M % 208 == 0 && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(M / 208, 208, N, K))
+        e = ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+      else
+        e = gemm128<Op>(ga, ep, st);
     } else if (epi_kind == 1) {
       const int d = N / 3;
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
-      e = gemm128<Op>(ga, ep, st);
+      if (M % 208 == 0 && ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(M / 208, 208, N, K))
+        e = ClipLaunch<Op, 3, 64, EpiQKV<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+      else
+        e = gemm128<Op>(ga, ep, st);
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
-      e = gemm128<Op>(ga, ep, st);
+      if (M % 208 == 0 && ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::applies(M / 208, 208, N, K))
+        e = ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+      else
+        e = gemm128<Op>(ga, ep, st);
     }
   }
   (void)hipEventRecord(e1, st);

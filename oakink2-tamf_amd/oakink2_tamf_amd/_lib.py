@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(_HERE, "lib", "libtamf_hip.so")
-SOURCES = ["tamf_hip.hip", "tamf_device.h", "tamf_gemm.h", "tamf_attn.h", "tamf_misc.h", "tamf_geom.h"]
+SOURCES = ["tamf_hip.hip", "tamf_device.h", "tamf_gemm.h", "tamf_gemm_clip.h", "tamf_attn.h", "tamf_misc.h", "tamf_geom.h"]
 
 _lock = threading.Lock()
 _lib = None

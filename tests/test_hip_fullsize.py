@@ -173,3 +173,45 @@ def test_refine_b64_t196_vs_oracle(prec):
     print(f"fullsize refine[{prec}]: max|err| = {err:.3e}")
     assert err < REFINE_TOL[prec], (prec, err)
     ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("N", [1536, 2048, 512])
+def test_gemm_clip_tiles_exact_integers(prec, N):
+    """Small-integer operands are exact in every arithmetic mode, so the clip-aligned tiles (one M tile = the 208 rows of
+    one clip; 192- / 256- / 128-column tiles for N = 1536 / 2048 / 512) must reproduce the integer product bit for bit:
+    any slip in the tile -> (clip, column) map, the slab-wise epilogue or the XCD remap shows up as a wrong integer."""
+    from oakink2_tamf_amd import hip_backend as hb
+
+    M, K = 13312, 128
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    b = torch.randint(-8, 9, (N,), generator=g).float()
+    got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), 0).cpu()
+    ref = (a.long() @ w.long().t() + b.long()).float()
+    assert torch.equal(got, ref), (prec, N, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_forward_clip_tiles_with_padded_rows(prec):
+    """T = 190 -> S = 195, padded to 200 rows per clip: the 208-row clip tile clamps its last 8 staged rows; B = 48 clips
+    (1.5 rounds of the 256 CUs).  Against the oracle on all clips."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM_L
+    B, T = 48, 190
+    sd = O.det_state_dict(arch, tag="full/w")
+    cond = O.det_cond(B, T, tag="pad/c", arch=arch)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 99, 1, T, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd, arch, x, t, cond)
+    ctx = _make_ctx(arch, sd, B, T, prec)
+    _set_cond(ctx, cond)
+    out = ctx.denoise(x, t).cpu()
+    err = float((out - ref).abs().max())
+    print(f"padded-rows forward[{prec}] B=48 T=190: max|err| = {err:.3e}")
+    assert err < FWD_TOL[prec], (prec, err)
+    ctx.close()
