@@ -3,20 +3,31 @@
 //   C[b*Sp + r][n] = sum_k A[b*Sp + r][k] * W[n][k]          one M tile = the Sp token rows of ONE clip
 //
 // Why its own kernel.  The 128 x 128 tiles of tamf_gemm.h stage (128 + 128) * 128 bytes from L2 per 128-byte K tile;
-// measured on MI355X (tools/kbench.py, ablation bits), their K loop is bound by the L2 -> LDS path of a CU (about
-// 70 GB/s per CU, MI355X_MICROARCH.md "Indexed rows: gather into LDS"), not by the matrix pipe: the loads alone take as
-// long as the MFMAs alone.  And M = 64 clips * 208 rows = 13 * 2^10 rows never fills 256 CUs evenly with power-of-two
-// row tiles (every launch ends in a 3.25th round).  A tile of one whole clip (208 rows = 13 MFMA row tiles) by 256 / 192 /
-// 128 columns stages (208 + BN) * 128 bytes per K tile for 208 * BN outputs - 1.8x / 1.6x / 1.25x the flops per staged
-// byte - and B = 64 clips give 512 / 512 / 256 tiles: exact rounds of the 256 CUs.
+// measured on MI355X (tools/kbench.py, ablation bits: loads alone take as long as the MFMAs alone), their K loop runs into
+// the L2 -> LDS path of a CU (about 70 GB/s per CU, MI355X_MICROARCH.md "Indexed rows: gather into LDS") as much as into the
+// matrix pipe.  And M = 64 clips * 208 rows = 13 * 2^10 rows never fills 256 CUs evenly with power-of-two row tiles (every
+// launch ends in a 3.25th round).  A tile of one whole clip (208 rows = 13 MFMA row tiles) by 256 / 192 / 128 columns stages
+// (208 + BN) * 128 bytes per K tile for 208 * BN outputs - 1.8x / 1.6x / 1.25x the flops per staged byte - and B = 64
+// clips give 512 / 512 / 256 tiles: exact rounds of the 256 CUs.
 //
-// Workgroup = 8 waves (one per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 own row tiles 0-6, waves 4-7
-// row tiles 7-12 (waves w and w + 4 share a SIMD, so every SIMD carries 7 + 6 row tiles), each over BN / 4 columns.
-// Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA pieces of 8 rows
-// x 128 bytes, source-side XOR swizzle, all fragments of a K tile requested up front, next tile's pieces issued after the
-// fragment reads).  Workgroups are persistent over their tiles; the first K tile of the next tile is requested before the
-// epilogue of the current one.  The accumulators are parked in LDS in slabs of 64 rows and handed to the same row-wise
-// epilogue functors as the other GEMMs.
+// Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 own row tiles 0-6,
+// waves 4-7 row tiles 7-12 (waves w and w + 4 share a SIMD, so every SIMD carries 7 + 6 row tiles), each over BN / 4
+// columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA pieces of
+// 8 rows x 128 bytes, source-side XOR swizzle, double-buffered stages, one barrier per K tile).
+//
+// The two waves of a SIMD run half a K tile apart.  Right after a barrier every wave would wait for its first fragments
+// (LDS latency) and then issue its share of the next K tile's 58 LDS-DMA pieces (the CU's address unit takes 16 cycles per
+// piece and a wave is blocked while its piece queues) - with all eight waves in those phases together the matrix pipe idles
+// for a third of each K tile (measured with the ablation bits of tools/kbench.py: fragment reads + barriers 1 180 cycles,
+// MFMAs 2 500, loads 700 per K tile, and the three ADD UP; QKV 76.8 us against 64.2 us on the small tiles, whose two
+// independent workgroups per CU cover each other).  So the waves of M half 0 ("X": waves 0-3) work as above - fragments of
+// K tile i, all DMA pieces of K tile i + 1, MFMAs of K tile i - while their SIMD partners ("Y": waves 4-7) spend the head of
+// the interval on the MFMAs of K tile i - 1, whose fragments they read into registers at the end of the previous interval,
+// and its tail on reading the fragments of K tile i.  The matrix pipe of every SIMD is fed by Y while X waits and issues, and
+// by X while Y reads; Y's fragments (its 6 row tiles + the column tiles: 80 registers) fit because Y owns one row tile less.
+//
+// Workgroups are persistent over their tiles.  The accumulators are parked in LDS in slabs of 64 rows and handed to the same
+// row-wise epilogue functors as the other GEMMs (their stores drain behind the next slab and the next tile's first K tiles).
 #pragma once
 #include "tamf_gemm.h"
 
@@ -29,6 +40,7 @@ struct ClipGemmArgs {
   int n_clips, Sp;  // A has n_clips * Sp rows; a tile covers rows [b*Sp, b*Sp + Sp)
   int N, K;
   int n_tiles;      // n_clips * (N / BN)
+  int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after a tile's first K tile, 2 = no MFMAs, 4 = no epilogue
 };
 
 template <int NSUB, int NI>
@@ -39,7 +51,6 @@ struct ClipCfg {
   static constexpr int ROWS = MT + BN;        // rows of one staged K tile: A rows then W rows
   static constexpr int STAGE = ROWS * GEMM_BKB;
   static constexpr int NPIECE = ROWS / 8, A_PIECES = MT / 8;
-  static constexpr int NPW = (NPIECE + 7) / 8;  // pieces per wave
   static constexpr int SLAB = 64;             // rows per epilogue slab
   static constexpr int LDC = BN + 4;
   static constexpr int C_OFF = STAGE;         // the C slab overlays stage 1: stage 0 stays free for the next tile's first K tile
@@ -48,43 +59,55 @@ struct ClipCfg {
   static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
-// source byte offsets of this lane's pieces of tile (clip b, column tile at n0): piece q = wave + 8 i covers staged rows
-// [8q, 8q + 8); rows < MT come from the clip's A rows (clamped to the clip), the others from the W rows of the column tile
+// Source addressing of the LDS-DMA pieces of one tile.  Piece q covers staged rows [8q, 8q + 8) (lane: row 8q + lane / 8,
+// 16-byte chunk lane % 8, XOR-swizzled by the row on the SOURCE side); rows < MT are the clip's A rows (clamped to the
+// clip), the others the W rows of the column tile.  A wave takes pieces q0, q0 + QS, q0 + 2 QS, ...: their rows are
+// 8 QS apart, a multiple of 16, so the swizzle term is the same for all of them and each piece's offset is one add.
+struct ClipSrc {
+  unsigned a0, a_last, w0;  // byte offsets from A / W of the lane's row in piece q0 (A: unclamped; clamped last row; W)
+};
 template <class Op, class C>
-TAMF_DEV void clip_tile_offsets(unsigned (&off)[C::NPW], const ClipGemmArgs<Op>& ga, int b, int n0, int wave, int prow, int pch) {
-#pragma unroll
-  for (int i = 0; i < C::NPW; ++i) {
-    const int row = (wave + 8 * i) * 8 + prow;
-    const int swz = (pch ^ swz_chunk<GEMM_BKB>(row)) << 4;
-    if (row < C::MT) {
-      const int r = row < ga.Sp ? row : ga.Sp - 1;
-      off[i] = (unsigned)(((long)b * ga.Sp + r) * ga.lda * Op::EB + swz);
-    } else {
-      const int wr = row - C::MT;
-      off[i] = (unsigned)((long)(n0 + (wr < C::BN ? wr : C::BN - 1)) * ga.ldw * Op::EB + swz);
-    }
-  }
+TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int q0, int prow, int pch) {
+  const int r0 = q0 * 8 + prow;
+  const unsigned swz = (unsigned)((pch ^ swz_chunk<GEMM_BKB>(r0)) << 4);
+  const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
+  ClipSrc s;
+  s.a0 = (unsigned)(b * ga.Sp + r0) * ldaB + swz;
+  s.a_last = (unsigned)(b * ga.Sp + ga.Sp - 1) * ldaB + swz;
+  s.w0 = (unsigned)(n0 + r0 - C::MT) * ldwB + swz;  // wraps for rows < MT, where it is not used
+  return s;
 }
-template <class C>
-TAMF_DEV void clip_issue(const unsigned (&off)[C::NPW], const char* Ab, const char* Wb, int kt, char* stage_base, int wave) {
+// issue pieces q0 + QS i (i = 0 .. ) of K tile kt into the stage at `stage_base`
+template <class Op, class C, int QS>
+TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int q0, int prow, int kt, char* stage_base) {
+  constexpr int NI_ = (C::NPIECE + QS - 1) / QS;
+  const char* Ab = (const char*)ga.A;
+  const char* Wb = (const char*)ga.W;
+  const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
 #pragma unroll
-  for (int i = 0; i < C::NPW; ++i) {
-    const int q = wave + 8 * i;
-    if (C::NPIECE % 8 == 0 || q < C::NPIECE) {
-      const char* src = (q < C::A_PIECES ? Ab : Wb) + off[i] + (long)kt * GEMM_BKB;
-      glds16<0>(src, stage_base + q * 1024);
+  for (int i = 0; i < NI_; ++i) {
+    const int q = q0 + QS * i;
+    if ((i + 1) * QS <= C::NPIECE || q < C::NPIECE) {
+      const char* src;
+      if (q < C::A_PIECES) {
+        const unsigned o = (q * 8 + prow < ga.Sp) ? s.a0 + (unsigned)(QS * 8 * i) * ldaB : s.a_last;
+        src = Ab + o;
+      } else {
+        src = Wb + (s.w0 + (unsigned)(QS * 8 * i) * ldwB);
+      }
+      glds16<0>(src + (long)kt * GEMM_BKB, stage_base + q * 1024);
     }
   }
 }
 
-// One K tile of one wave: request the next K tile into `nxt`, then multiply the tile in `cur`.  `cur` and `nxt` are the two
-// LDS stages and never overlap; the __restrict__ qualifiers of this (inlined) helper are what keeps hipcc from placing an
-// s_waitcnt vmcnt(0) in front of the LDS reads that follow the LDS-DMA in program order (same device as in tamf_attn.h), so
-// the A fragments can be streamed two row tiles ahead of their MFMAs instead of being held all at once (7 x 8 registers).
+// X waves, one K tile: the fragments of the first row tiles are requested, then ALL pieces of the next K tile go out into
+// `nxt`, then the MFMAs run with the A fragments streamed two row tiles ahead.  `cur` and `nxt` are the two LDS stages and
+// never overlap; the __restrict__ qualifiers of this (inlined) helper are what keeps hipcc from placing an s_waitcnt vmcnt(0)
+// in front of the LDS reads that follow the LDS-DMA in program order (as in tamf_attn.h).
 template <class Op, class C, int NI>
-TAMF_DEV void clip_ktile(const char* __restrict__ cur, char* __restrict__ nxt, bool more, const unsigned (&off)[C::NPW],
-                         const char* Ab, const char* Wb, int kt_next, int wave, int msub, int a_frag, int w_frag, int c0, int c1,
-                         f32x4 (&acc)[C::MSUB0][NI]) {
+TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt, bool load_next, bool compute,
+                           const ClipGemmArgs<Op>& ga, const ClipSrc& src4, int nq, int prow, int kt_next, int a_frag, int w_frag,
+                           int c0, int c1, f32x4 (&acc)[C::MSUB0][NI]) {
   constexpr int BKB = GEMM_BKB;
   int4 wf[NI][2];
 #pragma unroll
@@ -98,20 +121,44 @@ TAMF_DEV void clip_ktile(const char* __restrict__ cur, char* __restrict__ nxt, b
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
-  if (more) clip_issue<C>(off, Ab, Wb, kt_next, nxt, wave);
+  if (load_next) clip_issue<Op, C, 4>(ga, src4, nq, prow, kt_next, nxt);
 #pragma unroll
   for (int mi = 0; mi < C::MSUB0; ++mi) {
-    if (mi + 2 < C::MSUB0 && (mi + 2 < C::MSUB1 || mi + 2 < msub)) {
+    if (mi + 2 < C::MSUB0) {
       af[mi + 2][0] = *(const int4*)(cur + a_frag + (mi + 2) * 16 * BKB + c0);
       af[mi + 2][1] = *(const int4*)(cur + a_frag + (mi + 2) * 16 * BKB + c1);
     }
-    if (mi < C::MSUB1 || mi < msub) {
+    if (compute) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g + reg), cols = m (lr)
     }
   }
 }
+// Y waves: all fragments of a K tile into registers / the MFMAs on fragments read one interval earlier
+template <class C, int NI>
+TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c1, int4 (&wf)[NI][2], int4 (&af)[C::MSUB1][2]) {
+  constexpr int BKB = GEMM_BKB;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    wf[ni][0] = *(const int4*)(cur + w_frag + ni * 16 * BKB + c0);
+    wf[ni][1] = *(const int4*)(cur + w_frag + ni * 16 * BKB + c1);
+  }
+#pragma unroll
+  for (int mi = 0; mi < C::MSUB1; ++mi) {
+    af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
+    af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
+  }
+}
+template <class Op, class C, int NI>
+TAMF_DEV void clip_mma_y(const int4 (&wf)[NI][2], const int4 (&af)[C::MSUB1][2], f32x4 (&acc)[C::MSUB0][NI]) {
+#pragma unroll
+  for (int mi = 0; mi < C::MSUB1; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) Op::mma(acc[mi][ni], wf[ni], af[mi]);
+}
 
+// tile of this workgroup in round `r` of the persistent grid (-1: none): inside a round the XCDs own contiguous chunks of
+// the tile list (xcd_remap), i.e. a few whole clips x all their column tiles - a clip's A panel is fetched into one L2
 TAMF_DEV int clip_tile_of(int n_tiles, int round) {
   const int G = gridDim.x, base = round * G;
   if (base >= n_tiles) return -1;
@@ -129,11 +176,10 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int lr = lane & 15, g = lane >> 4;
   const int mh = wave >> 2, nq = wave & 3;
   const int msub = mh ? C::MSUB1 : C::MSUB0;
+  static_assert(C::MSUB0 == C::MSUB1 + 1 || C::MSUB0 == C::MSUB1, "row tiles per M half");
   const int wm0 = mh * C::MSUB0 * 16, wn0 = nq * (NI * 16);
   const int KT = (ga.K * Op::EB) / BKB;
   const int ntn = ga.N / C::BN;
-  const char* Ab = (const char*)ga.A;
-  const char* Wb = (const char*)ga.W;
   const int prow = lane >> 3, pch = lane & 7;
 
   // fragment addressing (as gemm_tile): lane (lr, g) reads chunks g and 4 + g of tile row lr (+16 per MFMA tile)
@@ -142,18 +188,15 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int a_frag = (wm0 + lr) * BKB;
   const int w_frag = (C::MT + wn0 + lr) * BKB;
 
-  unsigned off[C::NPW];
-
-  // tile of this workgroup in round `r` of the persistent grid (-1: none): inside a round the XCDs own contiguous chunks
-  // of the tile list (xcd_remap), i.e. a few whole clips x all their column tiles - a clip's A panel is fetched into one L2
   int round = 0;
   int t = clip_tile_of(ga.n_tiles, round);
   if (t < 0) return;
-  clip_tile_offsets<Op, C>(off, ga, t / ntn, (t % ntn) * C::BN, wave, prow, pch);
-  clip_issue<C>(off, Ab, Wb, 0, smem, wave);
+  // a tile's first K tile is requested by all eight waves (pieces wave, wave + 8, ...)
+  clip_issue<Op, C, 8>(ga, clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, wave, prow, pch), wave, prow, 0, smem);
   while (true) {
     const int b = t / ntn, n0 = (t % ntn) * C::BN;
     const int m0 = b * ga.Sp;
+    const ClipSrc src4 = clip_src<Op, C>(ga, b, n0, nq, prow, pch);  // loader role: pieces nq, nq + 4, ...
     f32x4 acc[C::MSUB0][NI];
 #pragma unroll
     for (int mi = 0; mi < C::MSUB0; ++mi)
@@ -161,23 +204,42 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // K tile 0 has landed (vmcnt(0) + barrier); the previous tile's C slab has been consumed
 
-    for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1;
-      clip_ktile<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, kt + 1 < KT, off, Ab, Wb, kt + 1, wave, msub,
-                            a_frag, w_frag, c0, c1, acc);
+    // KT + 1 barrier intervals: X multiplies K tile `it` in interval `it`, Y in interval `it + 1`.  Two separate loops
+    // (not one loop with a branch inside): Y's fragment registers are loop-carried and would otherwise be live - and spilled -
+    // across X's code.  Both loops execute the same KT + 1 barriers.
+    if (mh == 0) {
+      for (int it = 0; it < KT; ++it) {
+        const int cur = it & 1;
+        clip_ktile_x<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, (it + 1 < KT) && !(ga.abl & 1), !(ga.abl & 2), ga, src4,
+                                nq, prow, it + 1, a_frag, w_frag, c0, c1, acc);
+        __syncthreads();  // the next K tile has landed (vmcnt(0)); barrier
+      }
+      __syncthreads();
+    } else {
+      int4 ywf[NI][2], yaf[C::MSUB1][2];
+      clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
+      __syncthreads();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
+      for (int it = 1; it < KT; ++it) {
+        if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
+        clip_read_y<C, NI>(smem + (it & 1) * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
+        __syncthreads();
+      }
+      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
       __syncthreads();
     }
 
-    // the next tile's first K tile goes into stage 0 (last read at kt = KT - 2, KT is even) while this tile's epilogue runs
-    const int tn = clip_tile_of(ga.n_tiles, ++round);
-    const bool more = tn >= 0;
-    if (more) {
-      clip_tile_offsets<Op, C>(off, ga, tn / ntn, (tn % ntn) * C::BN, wave, prow, pch);
-      clip_issue<C>(off, Ab, Wb, 0, smem, wave);
-    }
-    // epilogue in slabs of 64 rows: a wave parks the row tiles it holds that fall into the slab, then all 8 waves walk it
+    // Epilogue in slabs of 64 rows: a wave parks the row tiles it holds that fall into the slab, then all 8 waves walk it.
+    // The slab barriers wait for the LDS only (s_waitcnt lgkmcnt(0) + s_barrier, not __syncthreads(), whose vmcnt(0) would
+    // wait for the acknowledgement of every global store of the slab before the next one may start), and the per-thread
+    // column constants (bias) are fetched once, ahead of the first store: vmcnt retires in order, so a load issued behind
+    // stores would wait for them just the same.
     float* Ct = (float*)(smem + C::C_OFF);
-    constexpr int NSLAB = (C::MT + C::SLAB - 1) / C::SLAB;
+    constexpr int NSLAB = (C::MT + C::SLAB - 1) / C::SLAB, NSUBN = C::BN / SUBN;
+    typename Epi::Cols cc[NSUBN];
+#pragma unroll
+    for (int ci = 0; ci < NSUBN; ++ci) cc[ci] = epi.template cols<SUBN, 512>(n0 + ci * SUBN, tid);
+#pragma unroll
+    for (int ci = 0; ci < NSUBN; ++ci) cc[ci].settle();
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
 #pragma unroll
@@ -191,13 +253,20 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           }
         }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       // column sub-blocks of SUBN for epilogues that decide per block (QKV: Q | K | V boundaries are multiples of 64)
+      if (!(ga.abl & 4)) {
 #pragma unroll
-      for (int cs = 0; cs < C::BN; cs += SUBN)
-        epi.template run<C::SLAB, SUBN, 512>(Ct + cs, C::LDC, m0 + sl * C::SLAB, n0 + cs, m0 + ga.Sp, tid);
-      __syncthreads();
+        for (int ci = 0; ci < NSUBN; ++ci)
+          epi.template run_c<C::SLAB, SUBN, 512>(Ct + ci * SUBN, C::LDC, m0 + sl * C::SLAB, n0 + ci * SUBN, m0 + ga.Sp, tid, cc[ci]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    // the next tile's first K tile (stage 0) is requested behind the epilogue: in front of it, hipcc would put a vmcnt(0) before
+    // every LDS access of the epilogue (it does so for any LDS access that follows an LDS-DMA in program order)
+    const int tn = clip_tile_of(ga.n_tiles, ++round);
+    const bool more = tn >= 0;
+    if (more) clip_issue<Op, C, 8>(ga, clip_src<Op, C>(ga, tn / ntn, (tn % ntn) * C::BN, wave, prow, pch), wave, prow, 0, smem);
     if (!more) break;
     t = tn;
   }

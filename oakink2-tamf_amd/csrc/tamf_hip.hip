@@ -303,7 +303,7 @@ struct ClipLaunch {
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN)};
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? (g_krot >> 12) & 7 : 0};
     const int cus = g_wg_slots / 2;
     hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, SUBN, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
@@ -804,7 +804,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
       EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
-      if (ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(B, Sp, 3 * d, d))
+      // (the clip tiles lose here - 192-column tiles, V^T epilogue: 72 against 63 us at B = 64 - and stay a benchmark option:
+      // tamf_set_gemm_tuning bit 0x400000, tools/step_ab.py)
+      if (g_krot >= 0 && (g_krot & 0x400000) && ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(B, Sp, 3 * d, d))
         HIPCHK(ctx, (ClipLaunch<Op, 3, 64, EpiQKV<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 3 * d, d, ep, st)));
       else
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
@@ -832,8 +834,8 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      const bool clip2 = ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(B, Sp, d, ff);
-      if ((Op::SPLIT || clip2) && ctx->tmp32) {
+      const bool clip2 = Op::SPLIT && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(B, Sp, d, ff);
+      if (Op::SPLIT && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
         if (clip2)
@@ -1239,6 +1241,8 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
         e = gemm128<Op>(ga, ep, st);
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
+      if (g_krot >= 0 && (g_krot & 0x8000)) ep.ldo = 0;   // ablation: every row stores to the same (L2-resident) row - no HBM writes
+      if (g_krot >= 0 && (g_krot & 0x20000)) ep.act = ACT_NONE;  // ablation: no GELU
       if (M % 208 == 0 && ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::applies(M / 208, 208, N, K))
         e = ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
       else
