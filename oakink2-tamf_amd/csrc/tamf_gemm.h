@@ -150,55 +150,15 @@ struct EpiQKV {
   typename Op::elem_t* vt;
   int d, H, hd, Sp, Skp;
   float qscale;
-  // per-thread column constants (see EpiBiasAct::Cols): the 8 bias values of the Q/K path, or the bias of the (at most 4)
-  // features a thread handles on the V^T path
-  struct Cols {
-    float b[8];
-    TAMF_DEV void settle() const {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(b[j]));
-    }
-  };
-  template <int BN, int NT>
-  TAMF_DEV Cols cols(int n0, int tid) const {
-    Cols c;
-    if (n0 < 2 * d || Op::PREC == 0) {
-      g_load8(bias + n0 + (tid % (BN / 8)) * 8, c.b);
-    } else {
-      constexpr int NB32 = 2;  // rows per call = 64 (all callers use BM = 64 or 128; the feature of iteration i is fixed by the wave)
-      const int lane = tid & 63, wv = tid >> 6, e_lo = lane >> 3;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int wi = wv + i * (NT / 64);
-        const int col = (wi / NB32) * 8 + e_lo;
-        c.b[i] = (i < 4 && col < BN) ? bias[n0 + col] : 0.f;
-      }
-    }
-    return c;
-  }
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    if constexpr (BM == 64) {
-      run_c<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, cols<BN, NT>(n0, tid));
-    } else {
-      run_c<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, Cols{});
-    }
-  }
-  // COLS_VT: the V^T bias values come from `cc` (BM == 64 only: two 32-row blocks per column group)
-  template <int BM, int BN, int NT>
-  TAMF_DEV void run_c(const float* Ct, int LDC, int m0, int n0, int M, int tid, const Cols& cc) const {
     if (n0 < 2 * d) {
       constexpr int VPR = BN / 8, RSTEP = NT / VPR;
       static_assert(NT % VPR == 0, "column group must be fixed per thread");
       const float sc = (n0 < d) ? qscale : 1.0f;
       const int col = (tid % VPR) * 8, gn = n0 + col;
       float b[8];
-      if constexpr (BM == 64) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = cc.b[j];
-      } else {
-        g_load8(bias + gn, b);
-      }
+      g_load8(bias + gn, b);
       for (int row = tid / VPR; row < BM; row += RSTEP) {
         const int gr = m0 + row;
         if (gr >= M) break;
@@ -233,20 +193,14 @@ struct EpiQKV {
       constexpr int NB32 = BM / 32, WITER = NB32 * (BN / 8);  // wave-iterations of the tile
       const int lane = tid & 63, wv = tid >> 6;
       const int e_lo = lane >> 3, u_lo = (lane >> 2) & 1, gq = lane & 3;
-      int i = 0;
-      for (int wi = wv; wi < WITER; wi += NT / 64, ++i) {
+      for (int wi = wv; wi < WITER; wi += NT / 64) {
         const int col = (wi / NB32) * 8 + e_lo, row0 = (wi % NB32) * 32 + u_lo * 16 + gq * 4;
         const int gr0 = m0 + row0;
         if (gr0 >= M) continue;
         const int eg = n0 - 2 * d + col;
         const int h = eg / hd, e = eg % hd;
         const int b = gr0 / Sp, s0 = gr0 % Sp;
-        float bb;
-        if constexpr (BM == 64 && WITER <= 4 * (NT / 64)) {
-          bb = i == 0 ? cc.b[0] : i == 1 ? cc.b[1] : i == 2 ? cc.b[2] : cc.b[3];
-        } else {
-          bb = bias[n0 + col];
-        }
+        const float bb = bias[n0 + col];
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;

@@ -1,4 +1,4 @@
-// Clip-aligned GEMM for the token-row GEMMs of the encoder layers (QKV, FFN1, FFN2):
+// Clip-aligned GEMM for the FFN GEMMs of the encoder layers (FFN1: 256-column tiles, FFN2: 128-column tiles):
 //
 //   C[b*Sp + r][n] = sum_k A[b*Sp + r][k] * W[n][k]          one M tile = the Sp token rows of ONE clip
 //
@@ -6,9 +6,11 @@
 // measured on MI355X (tools/kbench.py, ablation bits: loads alone take as long as the MFMAs alone), their K loop runs into
 // the L2 -> LDS path of a CU (about 70 GB/s per CU, MI355X_MICROARCH.md "Indexed rows: gather into LDS") as much as into the
 // matrix pipe.  And M = 64 clips * 208 rows = 13 * 2^10 rows never fills 256 CUs evenly with power-of-two row tiles (every
-// launch ends in a 3.25th round).  A tile of one whole clip (208 rows = 13 MFMA row tiles) by 256 / 192 / 128 columns stages
-// (208 + BN) * 128 bytes per K tile for 208 * BN outputs - 1.8x / 1.6x / 1.25x the flops per staged byte - and B = 64
-// clips give 512 / 512 / 256 tiles: exact rounds of the 256 CUs.
+// launch ends in a 3.25th round).  A tile of one whole clip (208 rows = 13 MFMA row tiles) by 256 / 128 columns stages
+// (208 + BN) * 128 bytes per K tile for 208 * BN outputs - 1.8x / 1.25x the flops per staged byte - and B = 64 clips give
+// 512 / 256 tiles: exact rounds of the 256 CUs.  (Measured against the small tiles at B = 64, f16x3, in situ: FFN1 78.7
+// against 86.4 us, FFN2 even; the QKV projection with 192-column tiles and its V^T epilogue lost - 72 against 63 us - and
+// stays on the 128 x 128 tiles.)
 //
 // Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 own row tiles 0-6,
 // waves 4-7 row tiles 7-12 (waves w and w + 4 share a SIMD, so every SIMD carries 7 + 6 row tiles), each over BN / 4
@@ -166,7 +168,7 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
   return (int)blockIdx.x < cnt ? base + xcd_remap(blockIdx.x, cnt) : -1;
 }
 
-template <class Op, int NSUB, int NI, int SUBN, class Epi>
+template <class Op, int NSUB, int NI, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
   typedef ClipCfg<NSUB, NI> C;
   constexpr int BKB = GEMM_BKB;
@@ -234,12 +236,9 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     // column constants (bias) are fetched once, ahead of the first store: vmcnt retires in order, so a load issued behind
     // stores would wait for them just the same.
     float* Ct = (float*)(smem + C::C_OFF);
-    constexpr int NSLAB = (C::MT + C::SLAB - 1) / C::SLAB, NSUBN = C::BN / SUBN;
-    typename Epi::Cols cc[NSUBN];
-#pragma unroll
-    for (int ci = 0; ci < NSUBN; ++ci) cc[ci] = epi.template cols<SUBN, 512>(n0 + ci * SUBN, tid);
-#pragma unroll
-    for (int ci = 0; ci < NSUBN; ++ci) cc[ci].settle();
+    constexpr int NSLAB = (C::MT + C::SLAB - 1) / C::SLAB;
+    const typename Epi::Cols cc = epi.template cols<C::BN, 512>(n0, tid);
+    cc.settle();
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
 #pragma unroll
@@ -254,12 +253,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // column sub-blocks of SUBN for epilogues that decide per block (QKV: Q | K | V boundaries are multiples of 64)
-      if (!(ga.abl & 4)) {
-#pragma unroll
-        for (int ci = 0; ci < NSUBN; ++ci)
-          epi.template run_c<C::SLAB, SUBN, 512>(Ct + ci * SUBN, C::LDC, m0 + sl * C::SLAB, n0 + ci * SUBN, m0 + ga.Sp, tid, cc[ci]);
-      }
+      if (!(ga.abl & 4)) epi.template run_c<C::SLAB, C::BN, 512>(Ct, C::LDC, m0 + sl * C::SLAB, n0, m0 + ga.Sp, tid, cc);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // the next tile's first K tile (stage 0) is requested behind the epilogue: in front of it, hipcc would put a vmcnt(0) before

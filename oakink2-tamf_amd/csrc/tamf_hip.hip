@@ -278,7 +278,7 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 // Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip.  Used when the clip has 13 MFMA row tiles (193..208 padded
 // rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
 // else runs on the 128 x 128 tiles.
-template <class Op, int NI, int SUBN, class Epi>
+template <class Op, int NI, class Epi>
 struct ClipLaunch {
   typedef ClipCfg<13, NI> C;
   static hipError_t prepare() {
@@ -286,7 +286,7 @@ struct ClipLaunch {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, SUBN, Epi>,
+    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::BYTES);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
@@ -305,7 +305,7 @@ struct ClipLaunch {
     if (e != hipSuccess) return e;
     ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? (g_krot >> 12) & 7 : 0};
     const int cus = g_wg_slots / 2;
-    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, SUBN, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
+    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
   }
 };
@@ -334,11 +334,9 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 3, 64, EpiQKV<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, 128, EpiStoreF32>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 4, 256, EpiStoreF32>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 3, 64, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -350,7 +348,10 @@ template <class Op>
 static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
   const int nqt = (aa.Sp + 15) / 16;
   const int nw_max = 16;  // one workgroup per (clip, head) up to 256 queries: K/V streamed once
-  const int chunks = (nqt + nw_max - 1) / nw_max;
+  int chunks = (nqt + nw_max - 1) / nw_max;
+  // fewer (clip, head) pairs than CUs (B = 32: 128): split the queries of a pair over workgroups until the chip is filled;
+  // K/V are then streamed once per workgroup, which costs less than idle CUs (a query's result does not depend on the split)
+  while (chunks * B * aa.H < g_wg_slots / 2 && chunks * 2 <= nqt) chunks *= 2;
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
   constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;
@@ -804,12 +805,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
       EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
-      // (the clip tiles lose here - 192-column tiles, V^T epilogue: 72 against 63 us at B = 64 - and stay a benchmark option:
-      // tamf_set_gemm_tuning bit 0x400000, tools/step_ab.py)
-      if (g_krot >= 0 && (g_krot & 0x400000) && ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(B, Sp, 3 * d, d))
-        HIPCHK(ctx, (ClipLaunch<Op, 3, 64, EpiQKV<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 3 * d, d, ep, st)));
-      else
-        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
@@ -826,20 +822,20 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
-      if (ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
-        HIPCHK(ctx, (ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+      if (ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
+        HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
       else
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      const bool clip2 = Op::SPLIT && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(B, Sp, d, ff);
+      const bool clip2 = Op::SPLIT && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
       if (Op::SPLIT && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
         if (clip2)
-          HIPCHK(ctx, (ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
+          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
         else
           HIPCHK(ctx, gemm128<Op>(ga, ep, st));
         mark("gemm_ffn2", BS * 2.0 * dd * ff);
@@ -1113,12 +1109,10 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
     EpiStoreF32 ep{bias, c, N, act};
     // M = n * 208 rows: the clip-aligned tiles the encoder layers use at T = 196 (same selection as enqueue_step)
     const int nc = M / 208;
-    if (M % 208 == 0 && N % 192 == 0 && ClipLaunch<Op, 3, 64, EpiStoreF32>::applies(nc, 208, N, Kp))
-      e = ClipLaunch<Op, 3, 64, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
-    else if (M % 208 == 0 && N % 256 == 0 && ClipLaunch<Op, 4, 256, EpiStoreF32>::applies(nc, 208, N, Kp))
-      e = ClipLaunch<Op, 4, 256, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
-    else if (M % 208 == 0 && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(nc, 208, N, Kp))
-      e = ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
+    if (M % 208 == 0 && N % 256 == 0 && ClipLaunch<Op, 4, EpiStoreF32>::applies(nc, 208, N, Kp))
+      e = ClipLaunch<Op, 4, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
+    else if (M % 208 == 0 && ClipLaunch<Op, 2, EpiStoreF32>::applies(nc, 208, N, Kp))
+      e = ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
     else
       e = gemm128<Op>(ga, ep, st);
   }
@@ -1228,23 +1222,20 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       e = gemm_ln<Op>(ga, ep, st);
     } else if (epi_kind == 3) {
       EpiStoreF32 ep{vec, x, N, ACT_NONE};
-      if (M % 208 == 0 && ClipLaunch<Op, 2, 128, EpiStoreF32>::applies(M / 208, 208, N, K))
-        e = ClipLaunch<Op, 2, 128, EpiStoreF32>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+      if (M % 208 == 0 && ClipLaunch<Op, 2, EpiStoreF32>::applies(M / 208, 208, N, K))
+        e = ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
       else
         e = gemm128<Op>(ga, ep, st);
     } else if (epi_kind == 1) {
       const int d = N / 3;
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
-      if (M % 208 == 0 && ClipLaunch<Op, 3, 64, EpiQKV<Op>>::applies(M / 208, 208, N, K))
-        e = ClipLaunch<Op, 3, 64, EpiQKV<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
-      else
-        e = gemm128<Op>(ga, ep, st);
+      e = gemm128<Op>(ga, ep, st);
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
       if (g_krot >= 0 && (g_krot & 0x8000)) ep.ldo = 0;   // ablation: every row stores to the same (L2-resident) row - no HBM writes
       if (g_krot >= 0 && (g_krot & 0x20000)) ep.act = ACT_NONE;  // ablation: no GELU
-      if (M % 208 == 0 && ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::applies(M / 208, 208, N, K))
-        e = ClipLaunch<Op, 4, 256, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+      if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(M / 208, 208, N, K))
+        e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
       else
         e = gemm128<Op>(ga, ep, st);
     }

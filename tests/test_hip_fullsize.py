@@ -178,9 +178,10 @@ def test_refine_b64_t196_vs_oracle(prec):
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("N", [1536, 2048, 512])
 def test_gemm_clip_tiles_exact_integers(prec, N):
-    """Small-integer operands are exact in every arithmetic mode, so the clip-aligned tiles (one M tile = the 208 rows of
-    one clip; 192- / 256- / 128-column tiles for N = 1536 / 2048 / 512) must reproduce the integer product bit for bit:
-    any slip in the tile -> (clip, column) map, the slab-wise epilogue or the XCD remap shows up as a wrong integer."""
+    """Small-integer operands are exact in every arithmetic mode, so the bench-shape launches - the clip-aligned tiles (one
+    M tile = the 208 rows of one clip; 256- / 128-column tiles for N = 2048 / 512) and the persistent 128 x 128 grid
+    (N = 1536) - must reproduce the integer product bit for bit: any slip in the tile -> (clip, column) map, the slab-wise
+    epilogue or the XCD remaps shows up as a wrong integer."""
     from oakink2_tamf_amd import hip_backend as hb
 
     M, K = 13312, 128
