@@ -12,9 +12,9 @@
 // against 86.4 us, FFN2 even; the QKV projection with 192-column tiles and its V^T epilogue lost - 72 against 63 us - and
 // stays on the 128 x 128 tiles.)
 //
-// Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 own row tiles 0-6,
-// waves 4-7 row tiles 7-12 (waves w and w + 4 share a SIMD, so every SIMD carries 7 + 6 row tiles), each over BN / 4
-// columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA pieces of
+// Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 ("X") own the first
+// XSUB row tiles, waves 4-7 ("Y") the other 13 - XSUB (waves w and w + 4 share a SIMD, so every SIMD carries all 13), each
+// over BN / 4 columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA pieces of
 // 8 rows x 128 bytes, source-side XOR swizzle, double-buffered stages, one barrier per K tile).
 //
 // The two waves of a SIMD run half a K tile apart.  Right after a barrier every wave would wait for its first fragments
@@ -33,6 +33,17 @@
 #pragma once
 #include "tamf_gemm.h"
 
+#ifdef TAMF_TIMELINE  // debug build (tools/clip_timeline.py): shader-clock stamps of waves 0 (X) and 4 (Y) of every workgroup
+__device__ unsigned long long g_clip_ts[512 * 2 * 8 * 4];  // [workgroup][X|Y][interval 4..11][4 stamps]
+#define TAMF_CLIP_TS(slot)                                                                     \
+  if (dbg_on) {                                                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
+    if (lane_dbg == 0) g_clip_ts[((blockIdx.x * 2 + mh_dbg) * 8 + (it_dbg - 4)) * 4 + (slot)] = t_; \
+  }
+#else
+#define TAMF_CLIP_TS(slot)
+#endif
+
 template <class Op>
 struct ClipGemmArgs {
   const typename Op::elem_t* A;
@@ -45,11 +56,13 @@ struct ClipGemmArgs {
   int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after a tile's first K tile, 2 = no MFMAs, 4 = no epilogue
 };
 
-template <int NSUB, int NI>
+template <int NSUB, int NI, int XSUB>
 struct ClipCfg {
   static constexpr int MT = NSUB * 16;        // tile rows (>= Sp)
   static constexpr int BN = 64 * NI;          // tile columns: 4 waves x NI MFMA column tiles
-  static constexpr int MSUB0 = (NSUB + 1) / 2, MSUB1 = NSUB - MSUB0;
+  // row tiles of the X waves (rows [0, 16 XSUB)) and of the Y waves (the rest); MSUB0 = the larger count (accumulator array)
+  static constexpr int MSUBX = XSUB, MSUBY = NSUB - XSUB;
+  static constexpr int MSUB0 = MSUBX > MSUBY ? MSUBX : MSUBY;
   static constexpr int ROWS = MT + BN;        // rows of one staged K tile: A rows then W rows
   static constexpr int STAGE = ROWS * GEMM_BKB;
   static constexpr int NPIECE = ROWS / 8, A_PIECES = MT / 8;
@@ -109,24 +122,27 @@ TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int q0, i
 template <class Op, class C, int NI>
 TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt, bool load_next, bool compute,
                            const ClipGemmArgs<Op>& ga, const ClipSrc& src4, int nq, int prow, int kt_next, int a_frag, int w_frag,
-                           int c0, int c1, f32x4 (&acc)[C::MSUB0][NI]) {
+                           int c0, int c1, f32x4 (&acc)[C::MSUB0][NI], bool dbg_on = false, int it_dbg = 0, int lane_dbg = 0) {
   constexpr int BKB = GEMM_BKB;
+  constexpr int mh_dbg = 0;
+  (void)dbg_on; (void)it_dbg; (void)lane_dbg; (void)mh_dbg;
   int4 wf[NI][2];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     wf[ni][0] = *(const int4*)(cur + w_frag + ni * 16 * BKB + c0);
     wf[ni][1] = *(const int4*)(cur + w_frag + ni * 16 * BKB + c1);
   }
-  int4 af[C::MSUB0][2];
+  int4 af[C::MSUBX][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
   if (load_next) clip_issue<Op, C, 4>(ga, src4, nq, prow, kt_next, nxt);
+  TAMF_CLIP_TS(1)
 #pragma unroll
-  for (int mi = 0; mi < C::MSUB0; ++mi) {
-    if (mi + 2 < C::MSUB0) {
+  for (int mi = 0; mi < C::MSUBX; ++mi) {
+    if (mi + 2 < C::MSUBX) {
       af[mi + 2][0] = *(const int4*)(cur + a_frag + (mi + 2) * 16 * BKB + c0);
       af[mi + 2][1] = *(const int4*)(cur + a_frag + (mi + 2) * 16 * BKB + c1);
     }
@@ -138,7 +154,7 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
 }
 // Y waves: all fragments of a K tile into registers / the MFMAs on fragments read one interval earlier
 template <class C, int NI>
-TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c1, int4 (&wf)[NI][2], int4 (&af)[C::MSUB1][2]) {
+TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c1, int4 (&wf)[NI][2], int4 (&af)[C::MSUBY][2]) {
   constexpr int BKB = GEMM_BKB;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -146,15 +162,15 @@ TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c
     wf[ni][1] = *(const int4*)(cur + w_frag + ni * 16 * BKB + c1);
   }
 #pragma unroll
-  for (int mi = 0; mi < C::MSUB1; ++mi) {
+  for (int mi = 0; mi < C::MSUBY; ++mi) {
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
 }
 template <class Op, class C, int NI>
-TAMF_DEV void clip_mma_y(const int4 (&wf)[NI][2], const int4 (&af)[C::MSUB1][2], f32x4 (&acc)[C::MSUB0][NI]) {
+TAMF_DEV void clip_mma_y(const int4 (&wf)[NI][2], const int4 (&af)[C::MSUBY][2], f32x4 (&acc)[C::MSUB0][NI]) {
 #pragma unroll
-  for (int mi = 0; mi < C::MSUB1; ++mi)
+  for (int mi = 0; mi < C::MSUBY; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) Op::mma(acc[mi][ni], wf[ni], af[mi]);
 }
@@ -168,18 +184,18 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
   return (int)blockIdx.x < cnt ? base + xcd_remap(blockIdx.x, cnt) : -1;
 }
 
-template <class Op, int NSUB, int NI, class Epi>
+template <class Op, int NSUB, int NI, int XSUB, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
-  typedef ClipCfg<NSUB, NI> C;
+  typedef ClipCfg<NSUB, NI, XSUB> C;
   constexpr int BKB = GEMM_BKB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;  // (& 7: lets the compiler fold the piece bounds)
   const int lr = lane & 15, g = lane >> 4;
   const int mh = wave >> 2, nq = wave & 3;
-  const int msub = mh ? C::MSUB1 : C::MSUB0;
-  static_assert(C::MSUB0 == C::MSUB1 + 1 || C::MSUB0 == C::MSUB1, "row tiles per M half");
-  const int wm0 = mh * C::MSUB0 * 16, wn0 = nq * (NI * 16);
+  const int msub = mh ? C::MSUBY : C::MSUBX;
+  static_assert(C::MSUBX >= 2 && C::MSUBY >= 1, "row tiles per wave half");
+  const int wm0 = mh * C::MSUBX * 16, wn0 = nq * (NI * 16);
   const int KT = (ga.K * Op::EB) / BKB;
   const int ntn = ga.N / C::BN;
   const int prow = lane >> 3, pch = lane & 7;
@@ -212,21 +228,52 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     if (mh == 0) {
       for (int it = 0; it < KT; ++it) {
         const int cur = it & 1;
+#ifdef TAMF_TIMELINE
+        const bool dbg_on = wave == 0 && round == 0 && it >= 4 && it < 12 && blockIdx.x < 512;
+        const int it_dbg = it, lane_dbg = lane, mh_dbg = 0;
+        TAMF_CLIP_TS(0)
+        clip_ktile_x<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, (it + 1 < KT) && !(ga.abl & 1), !(ga.abl & 2), ga, src4,
+                                nq, prow, it + 1, a_frag, w_frag, c0, c1, acc, dbg_on, it_dbg, lane_dbg);
+        TAMF_CLIP_TS(2)
+        __syncthreads();
+        TAMF_CLIP_TS(3)
+#else
         clip_ktile_x<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, (it + 1 < KT) && !(ga.abl & 1), !(ga.abl & 2), ga, src4,
                                 nq, prow, it + 1, a_frag, w_frag, c0, c1, acc);
         __syncthreads();  // the next K tile has landed (vmcnt(0)); barrier
+#endif
       }
       __syncthreads();
     } else {
-      int4 ywf[NI][2], yaf[C::MSUB1][2];
+      // Y's MFMAs go first on the SIMD (static priority, no per-interval flips): they are ready at the top of the interval,
+      // while X spends its head on the DMA pieces anyway; served from the leftovers of the older X wave (equal priority:
+      // the older wave wins arbitration) Y finished LAST - 2 620 of 3 300 cycles - and its fragment reads and the barrier
+      // followed with the matrix pipe idle.  With priority Y is done after ~1 200 cycles and reads while X multiplies.
+      __builtin_amdgcn_s_setprio(2);
+      int4 ywf[NI][2], yaf[C::MSUBY][2];
       clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
       __syncthreads();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
       for (int it = 1; it < KT; ++it) {
+#ifdef TAMF_TIMELINE
+        const bool dbg_on = wave == 4 && round == 0 && it >= 4 && it < 12 && blockIdx.x < 512;
+        const int it_dbg = it, lane_dbg = lane, mh_dbg = 1;
+#endif
+        TAMF_CLIP_TS(0)
         if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
+#ifdef TAMF_TIMELINE
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
+#endif
+        TAMF_CLIP_TS(1)
         clip_read_y<C, NI>(smem + (it & 1) * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
+#ifdef TAMF_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        TAMF_CLIP_TS(2)
         __syncthreads();
+        TAMF_CLIP_TS(3)
       }
       if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
     }
 
@@ -243,8 +290,8 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     for (int sl = 0; sl < NSLAB; ++sl) {
 #pragma unroll
       for (int mi = 0; mi < C::MSUB0; ++mi) {
-        const int s = mh * C::MSUB0 + mi;  // row tile of the clip
-        if ((mi < C::MSUB1 || mi < msub) && (s >> 2) == sl) {
+        const int s = mh * C::MSUBX + mi;  // row tile of the clip
+        if (mi < msub && (s >> 2) == sl) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             const f32x4 v = acc[mi][ni];

@@ -278,15 +278,18 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 // Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip.  Used when the clip has 13 MFMA row tiles (193..208 padded
 // rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
 // else runs on the 128 x 128 tiles.
+// row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the 13 row tiles
+template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? 6 : 4; };  // (5 : 8 spills the Y waves at 256 columns)
 template <class Op, int NI, class Epi>
 struct ClipLaunch {
-  typedef ClipCfg<13, NI> C;
+  static constexpr int XSUB = ClipXsub<NI>::value;
+  typedef ClipCfg<13, NI, XSUB> C;
   static hipError_t prepare() {
     static bool done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, Epi>,
+    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, XSUB, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::BYTES);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
@@ -305,7 +308,7 @@ struct ClipLaunch {
     if (e != hipSuccess) return e;
     ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? (g_krot >> 12) & 7 : 0};
     const int cus = g_wg_slots / 2;
-    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
+    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
   }
 };
@@ -1359,6 +1362,7 @@ extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t dra
 // debug builds only (not part of include/tamf_hip.h): which = 0 GEMM (5 u64 per workgroup), 1 attention (4 u64)
 extern "C" int tamf_debug_timeline(int which, void* dst, size_t bytes) {
   if (which == 0) return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_ts), bytes, 0, hipMemcpyDeviceToHost);
+  if (which == 2) return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_clip_ts), bytes, 0, hipMemcpyDeviceToHost);
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_ts), bytes, 0, hipMemcpyDeviceToHost);
 }
 #endif
