@@ -21,6 +21,23 @@ __device__ __forceinline__ unsigned long long tamf_hw_cu_id() {  // (XCC id << 3
 #define TAMF_TS(var)
 #endif
 
+// Wide global stores of the streaming outputs (activation operands, the residual stream): plain stores.  Write-through
+// (sc1) and nt stores were measured on the whole loop and lose 10 % (2.63 -> 2.89 / 2.86 ms per step, f16x3): the consumers
+// of X_op / QK_op / A_op find a good part of them in the writer's L2, which a write-through store gives up.
+typedef uint32_t tamf_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tamf_u32x2 __attribute__((ext_vector_type(2)));
+TAMF_DEV void gst16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  const tamf_u32x4 v = {a, b, c, d};
+  *(tamf_u32x4*)p = v;
+}
+TAMF_DEV void gst8(void* p, uint32_t a, uint32_t b) {
+  const tamf_u32x2 v = {a, b};
+  *(tamf_u32x2*)p = v;
+}
+TAMF_DEV void gst16f(float* p, float a, float b, float c, float d) {
+  gst16(p, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
+}
+
 TAMF_DEV uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
 TAMF_DEV float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
 // two floats -> packed bf16 pair (round to nearest even; one v_cvt_pk_bf16_f32), element 0 in the low half
@@ -133,10 +150,10 @@ struct OpF32 {
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     float* p = base + idx;
     if constexpr (N == 8) {
-      *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-      *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      gst16f(p, v[0], v[1], v[2], v[3]);
+      gst16f(p + 4, v[4], v[5], v[6], v[7]);
     } else if constexpr (N == 4) {
-      *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+      gst16f(p, v[0], v[1], v[2], v[3]);
     } else {
       *(float2*)p = make_float2(v[0], v[1]);
     }
@@ -148,9 +165,9 @@ struct OpF32 {
 template <int N>
 TAMF_DEV void store_bf16_vec(char* p, const uint32_t* w) {
   if constexpr (N == 8) {
-    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    gst16(p, w[0], w[1], w[2], w[3]);
   } else if constexpr (N == 4) {
-    *(uint2*)p = make_uint2(w[0], w[1]);
+    gst8(p, w[0], w[1]);
   } else {
     *(uint32_t*)p = w[0];
   }

@@ -63,8 +63,8 @@ TAMF_DEV void g_load8(const float* p, float (&v)[8]) {
   v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
-  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  gst16f(p, v[0], v[1], v[2], v[3]);
+  gst16f(p + 4, v[4], v[5], v[6], v[7]);
 }
 
 // out = act(C + bias[n] + rowadd[m][n]) stored as an operand (FFN1+GELU, input_merge.0+SiLU, hoisted GEMMs)
@@ -315,10 +315,10 @@ struct EpiLN {
       for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * ga[j] + be[j];
       float* op = xout + (long)gr * BN + c0;
       if constexpr (VPL == 8) {
-        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        gst16f(op, v[0], v[1], v[2], v[3]);
+        gst16f(op + 4, v[4], v[5], v[6], v[7]);
       } else if constexpr (VPL == 4) {
-        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+        gst16f(op, v[0], v[1], v[2], v[3]);
       } else {
         *(float2*)op = make_float2(v[0], v[1]);
       }

@@ -199,6 +199,9 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // from the 4 MB L2 by the other GEMMs of the layer: 186 -> 153 us in situ), the 128 x 128 tiles do not (it costs them
 // 5-8 %).  Only the kernel benchmark hook (tamf_bench_gemm) overrides it.
 static int g_krot = -1;
+// kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
+// 2 = FFN2 on the 128 x 128 tiles, 8 = FFN1 on the 128 x 128 tiles
+static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
 // resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch
@@ -295,7 +298,7 @@ struct ClipLaunch {
     return e;
   }
   static bool applies(int n_clips, int Sp, int N, int K) {
-    if (g_krot >= 0 && (g_krot & 0x100000)) return false;  // kernel benchmark hook: force the 128 x 128 tiles (A/B runs)
+    if (g_sel & 1) return false;  // kernel benchmark hook: force the 128 x 128 tiles (A/B runs)
     if (Sp > C::MT || Sp <= C::MT - 16 || N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
     const int KT = (K * Op::EB) / GEMM_BKB;
     if (KT < 2 || (KT & 1)) return false;
@@ -825,7 +828,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
-      if (ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
+      if (!(g_sel & 8) && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
         HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
       else
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
@@ -833,7 +836,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      const bool clip2 = Op::SPLIT && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
+      const bool clip2 = Op::SPLIT && !(g_sel & 2) && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
       if (Op::SPLIT && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
@@ -1259,13 +1262,14 @@ extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot
                                int32_t iters, float* ms_out, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
   if (epi_kind == 1 && (N % 384 || M % 208)) return fail(nullptr, TAMF_ERR_INVALID, "qkv bench needs N = 3d, M multiple of 208");
-  const int saved_rot = g_krot;
-  g_krot = krot;  // -1 = per-kernel default; >= 0 = GemmArgs::krot bits (tamf_gemm.h)
+  const int saved_rot = g_krot, saved_sel = g_sel;
+  tamf_set_gemm_tuning(krot);  // -1 = per-kernel defaults; >= 0 = GemmArgs::krot bits (tamf_gemm.h) + selection overrides
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
   if (precision < 0 || precision > TAMF_PREC_F16X3) rc = fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   else TAMF_WITH_OP(precision, rc = bench_gemm_impl<Op>(epi_kind, M, N, K, iters, ms_out, st));
   g_krot = saved_rot;
+  g_sel = saved_sel;
   return rc;
 }
 
@@ -1344,7 +1348,9 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 }
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
-  g_krot = krot;
+  // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..23: kernel-selection overrides
+  g_sel = krot >= 0 ? (krot >> 20) & 0xF : 0;
+  g_krot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
   return 0;
 }
 

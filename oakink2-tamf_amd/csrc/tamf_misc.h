@@ -125,9 +125,13 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    v[j] = (v[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
-    xout[(long)row * D + c0 + j] = v[j];
+  for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+  if constexpr (VPL % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < VPL; j += 4) gst16f(xout + (long)row * D + c0 + j, v[j], v[j + 1], v[j + 2], v[j + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) xout[(long)row * D + c0 + j] = v[j];
   }
   Op::template store<VPL>(xop, (long)row * D + c0, v);
 }
