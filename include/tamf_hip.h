@@ -155,6 +155,14 @@ int tamf_contact_min_dist(const float* hand_verts_dev, const float* obj_traj_dev
  * is_f64: 0 = float32 buffers, 1 = float64 buffers. */
 int tamf_transform_points(const void* obj_traj_dev, const void* obj_points_dev, int32_t n_obj, int32_t T, int32_t P,
                           int32_t is_f64, void* out_dev, void* stream);
+/* Vertex normals of a mesh sequence (model/segment_refine_model.py:131-133: pytorch3d Meshes(verts, faces).verts_normals_packed()
+ * of the MANO hand; pytorch3d 0.7.2 _compute_vertex_normals: area-weighted face normals summed per vertex, x / max(|x|, 1e-6)).
+ * verts (n_mesh, V, 3) f32; the incidence list of the (fixed) topology in CSR form, built by the caller from faces (F,3):
+ * csr_off (V + 1) int32, csr_ent (2 * 3F) int32 = for every corner (face f, corner c) of vertex faces[f][c] the pair
+ * (faces[f][(c+1)%3], faces[f][(c+2)%3]), ordered corner 1 / corner 2 / corner 0, faces ascending (oakink2_tamf_amd.geometry
+ * .vertex_normals builds it); normals_out (n_mesh, V, 3) f32. */
+int tamf_vertex_normals(const float* verts_dev, int64_t n_mesh, int32_t V, const int32_t* csr_off_dev, const int32_t* csr_ent_dev,
+                        float* normals_out_dev, void* stream);
 /* Point-in-closed-mesh test of the Solid-Intersection-Volume score (script/compute_score/compute_score_siv.py:128-153 ->
  * dev_fn/external/libmesh/inside_mesh.py:8-149 check_mesh_contains, whose Cython TriangleHash is an acceleration structure
  * only): float64, the reference's operation order, no fused multiply-adds - the result is bit-identical to numpy's.

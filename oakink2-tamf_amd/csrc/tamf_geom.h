@@ -240,3 +240,38 @@ __global__ void transform_points_kernel(const T* __restrict__ traj, const T* __r
     op[j * 3 + 2] = b3x * x + b3y * y + b3z * z + tz;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Vertex normals of a triangle mesh sequence (the MANO hand: 778 vertices, 1 538 faces; segment_refine_model.py:131-133
+// -> pytorch3d Meshes.verts_normals_packed, pytorch3d 0.7.2 structures/meshes.py _compute_vertex_normals):
+//     n[v] = normalize( sum over the corners (f, c) with faces[f][c] == v of cross(x[next] - x[v], x[prev] - x[v]) ),
+// next / prev = the face's following / preceding corner, i.e. every incident face contributes its area-weighted normal,
+// computed with v as the pivot; normalize = x / max(|x|, 1e-6).  Gather form: the topology is fixed, so the host builds
+// the incidence list once (CSR: off[V + 1], ent[2 * 3F] = (next, prev) vertex ids, ordered as index_add_ visits them on
+// the CPU: corner 1 of all faces, then corner 2, then corner 0, faces ascending) and a thread sums its vertex's entries
+// in that order - deterministic, no atomics.  No FMA contraction: the sums match the sequential CPU evaluation bit for bit.
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void vertex_normals_kernel(const float* __restrict__ verts, const int* __restrict__ off, const int* __restrict__ ent,
+                                      float* __restrict__ out, long n_mesh, int V) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_mesh * V) return;
+  const int v = (int)(idx % V);
+  const float* x = verts + (idx / V) * (long)V * 3;
+  const float px = x[3 * v], py = x[3 * v + 1], pz = x[3 * v + 2];
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  for (int e = off[v]; e < off[v + 1]; ++e) {
+    const int a = ent[2 * e], b = ent[2 * e + 1];
+    const float ax = x[3 * a] - px, ay = x[3 * a + 1] - py, az = x[3 * a + 2] - pz;
+    const float bx = x[3 * b] - px, by = x[3 * b + 1] - py, bz = x[3 * b + 2] - pz;
+    nx = nx + (ay * bz - az * by);
+    ny = ny + (az * bx - ax * bz);
+    nz = nz + (ax * by - ay * bx);
+  }
+  const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+  const float den = len > 1e-6f ? len : 1e-6f;
+  out[idx * 3] = nx / den;
+  out[idx * 3 + 1] = ny / den;
+  out[idx * 3 + 2] = nz / den;
+}
+#pragma clang fp contract(fast)

@@ -1330,6 +1330,17 @@ extern "C" int tamf_transform_points(const void* obj_traj_dev, const void* obj_p
   return 0;
 }
 
+extern "C" int tamf_vertex_normals(const float* verts_dev, int64_t n_mesh, int32_t V, const int32_t* csr_off_dev,
+                                    const int32_t* csr_ent_dev, float* normals_out_dev, void* stream) {
+  if (!verts_dev || !csr_off_dev || !csr_ent_dev || !normals_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
+  if (n_mesh <= 0 || V <= 0) return fail(nullptr, TAMF_ERR_INVALID, "bad shape");
+  hipLaunchKernelGGL(vertex_normals_kernel, grid1d((long)n_mesh * V), dim3(256), 0, (hipStream_t)stream, verts_dev, csr_off_dev,
+                     csr_ent_dev, normals_out_dev, (long)n_mesh, V);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, const double* points_dev,
                                   int64_t n_points, const double* scale3, const double* translate3, int32_t resolution,
                                   double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream) {

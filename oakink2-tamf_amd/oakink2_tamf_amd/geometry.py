@@ -7,6 +7,8 @@ multi_object_h2o_dist  reference: SegmentRefineModel.multi_object_h2o_dist (mode
 contact_min_dist       reference: transf_merge_obj_pointcloud + contact_min_cdist (script/compute_score/compute_score_cr.py:122-149),
 contact_ratio          the Contact-Ratio score built on it (:282-283, threshold 5 mm)
 transform_points       reference: tslrot6d_to_transf_np + transf_point_array_np (dev_fn/transform/transform_np.py:169-175,36-53)
+vertex_normals         reference: Meshes(verts, faces).verts_normals_packed() of the MANO hand (model/segment_refine_model.py:131-133;
+                       pytorch3d 0.7.2 _compute_vertex_normals)
 mesh_contains          reference: check_mesh_contains (dev_fn/external/libmesh/inside_mesh.py:8-149 + Cython TriangleHash),
 solid_intersection_volume  the SIV score built on it (script/compute_score/compute_score_siv.py:128-153)
 All return torch tensors on the inputs' device; no CPU fallback."""
@@ -28,6 +30,7 @@ def _bind():
     L.tamf_h2o_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
     L.tamf_contact_min_dist.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p]
     L.tamf_transform_points.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    L.tamf_vertex_normals.argtypes = [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
     L.tamf_mesh_contains.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
                                      c_void_p, c_void_p]
     return L
@@ -86,6 +89,49 @@ def contact_ratio(min_dist: torch.Tensor, valid_len: Optional[Sequence[int]] = N
         keep = torch.arange(d.shape[1], device=d.device)[None, :] < torch.as_tensor(list(valid_len), device=d.device)[:, None]
         d = d[keep]
     return float((d < threshold).double().mean())
+
+
+_CSR_CACHE = {}
+
+
+def vertex_incidence_csr(faces, n_verts: int):
+    """faces (F,3) int -> (off (V+1,), ent (3F,2)) int32 numpy: for every vertex the (next, prev) vertex pairs of its face
+    corners, in the order index_add_ accumulates them on the CPU: corner 1 of all faces, then corner 2, then corner 0."""
+    import numpy as np
+
+    f = np.asarray(faces.detach().cpu().numpy() if isinstance(faces, torch.Tensor) else faces).astype(np.int64)
+    F = f.shape[0]
+    owner = np.concatenate([f[:, 1], f[:, 2], f[:, 0]])
+    nxt = np.concatenate([f[:, 2], f[:, 0], f[:, 1]])
+    prv = np.concatenate([f[:, 0], f[:, 1], f[:, 2]])
+    order = np.argsort(owner, kind="stable")  # stable: keeps the pass / face order inside a vertex
+    off = np.zeros(n_verts + 1, np.int32)
+    np.cumsum(np.bincount(owner, minlength=n_verts), out=off[1:])
+    ent = np.stack([nxt[order], prv[order]], axis=1).astype(np.int32)
+    assert ent.shape[0] == 3 * F
+    return off, np.ascontiguousarray(ent)
+
+
+def vertex_normals(verts: torch.Tensor, faces) -> torch.Tensor:
+    """verts (..., V, 3), faces (F, 3) -> unit vertex normals (..., V, 3): area-weighted face normals summed per vertex
+    (pytorch3d's verts_normals_packed for every mesh of the sequence)."""
+    dev = require_gpu(verts.device)
+    v = _dev_f32(verts, dev)
+    V = int(v.shape[-2])
+    f_t = faces if isinstance(faces, torch.Tensor) else torch.as_tensor(faces)
+    key = (f_t.data_ptr() if f_t.is_cuda or f_t.is_cpu else 0, tuple(f_t.shape), V, str(dev), int(f_t.sum()), int((f_t.double() ** 2).sum()))
+    hit = _CSR_CACHE.get(key)
+    if hit is None:
+        off, ent = vertex_incidence_csr(f_t, V)
+        hit = (torch.from_numpy(off).to(dev), torch.from_numpy(ent).to(dev), f_t)  # (f_t kept alive with its key)
+        _CSR_CACHE.clear()
+        _CSR_CACHE[key] = hit
+    n = v.numel() // (V * 3)
+    out = torch.empty_like(v)
+    with torch.cuda.device(dev):
+        _check(_bind().tamf_vertex_normals(c_void_p(v.data_ptr()), n, V, c_void_p(hit[0].data_ptr()), c_void_p(hit[1].data_ptr()),
+                                           c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return out
 
 
 def mesh_contains(verts, faces, points: torch.Tensor, resolution: int = 512) -> torch.Tensor:

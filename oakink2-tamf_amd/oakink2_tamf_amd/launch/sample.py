@@ -25,6 +25,7 @@ import numpy as np
 
 from ..hip_backend import hand_side_code
 from .formats import write_sample_npy
+from .upkeep import ckpt_opt, ckpt_setup, decode_file_macro
 
 _logger = logging.getLogger("oakink2_tamf_amd.launch.sample")
 PROG = "sample"
@@ -75,7 +76,9 @@ def parse_args(argv: List[str]):
 def build_config(known, dotted) -> Dict:
     import yaml
 
-    cfg: Dict = {"model": dict(MODEL_DEFAULTS), "data": {}, "debug": {}, "runtime": {"num_worker": None, "device_id": [0], "batch_size": 64}}
+    # runtime defaults of the reference (launch/sample.py:114-127): 8 workers over devices 0-3; main() clamps both to the
+    # devices and clips that exist
+    cfg: Dict = {"model": dict(MODEL_DEFAULTS), "data": {}, "debug": {}, "runtime": {"num_worker": 8, "device_id": [0, 1, 2, 3], "batch_size": 64}}
     for path in known.cfg:
         with open(path) as f:
             _merge(cfg, yaml.safe_load(f) or {})
@@ -87,6 +90,8 @@ def build_config(known, dotted) -> Dict:
             v = typ(v)
         elif k in ("runtime.num_worker", "runtime.batch_size"):
             v = int(v)
+        elif k == "data.process_range":  # comma list; ?(file:<path>) entries expand to the file's lines (upkeep.decode_file_macro)
+            v = decode_file_macro([x for x in str(v).split(",") if x != ""])
         _set_dotted(cfg, k, v)
     cfg["exp_id"] = known.exp_id
     cfg["commit"] = known.commit
@@ -112,8 +117,19 @@ def load_conditioning(cfg, known):
         raise SystemExit(
             "no clips to sample: the OakInk2 dataset toolkit (thirdparty/OakInk2) is not available in this build; pass "
             "--data.cond_npz <file> with pre-collated conditioning tensors or --synthetic B,T")
-    with np.load(path) as z:
-        return {k: z[k] for k in ("text_embedding", "hand_side", "shape", "obj_embedding", "obj_traj")}
+    with np.load(path, allow_pickle=False) as z:
+        cond = {k: z[k] for k in ("text_embedding", "hand_side", "shape", "obj_embedding", "obj_traj")}
+        keys = z["process_key"] if "process_key" in z.files else None
+    pr = cfg["data"].get("process_range")
+    if pr is not None:
+        # the reference walks the dataset's clips of the listed process keys (launch/sample.py:161-166); here the clips
+        # are the rows of the .npz, selected by its `process_key` column
+        if keys is None:
+            raise SystemExit("--data.process_range needs a `process_key` array in --data.cond_npz")
+        want = set(pr)
+        sel = np.array([i for i, k in enumerate(keys) if str(k.decode() if isinstance(k, bytes) else k) in want], dtype=np.int64)
+        cond = {k: v[sel] for k, v in cond.items()}
+    return cond
 
 
 def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, cond: Dict, known_seed: int, precision: str,
@@ -169,16 +185,16 @@ def main(argv=None):
     known, dotted = parse_args(sys.argv[1:] if argv is None else argv)
     cfg = build_config(known, dotted)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
-    if cfg["commit"]:
-        import yaml
-
-        os.makedirs(cfg["ckpt_path"], exist_ok=True)
-        with open(os.path.join(cfg["ckpt_path"], "opt.yml"), "w") as f:
-            yaml.safe_dump({k: v for k, v in cfg.items()}, f)
+    ckpt_setup(cfg, argv=sys.argv[1:] if argv is None else argv)
+    ckpt_opt(cfg)
     cond = load_conditioning(cfg, known)
-    device_ids = cfg["runtime"]["device_id"]
-    num_worker = cfg["runtime"].get("num_worker") or len(device_ids)
+    import torch
     import torch.multiprocessing as mp
+
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+    device_ids = [d for d in cfg["runtime"]["device_id"] if d < max(n_dev, 1)] or [0]
+    n_clips = int(cond["shape"].shape[0])
+    num_worker = max(1, min(int(cfg["runtime"].get("num_worker") or len(device_ids)), n_clips))
 
     if num_worker == 1:
         sample_worker(0, 1, device_ids[0], cfg, cond, known.seed, known.precision, known.diffusion_steps)

@@ -113,6 +113,9 @@ def main(argv=None):
     known, dotted = parse_args(sys.argv[1:] if argv is None else argv)
     cfg = build_config(known, dotted)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
+    from .upkeep import ckpt_opt, ckpt_setup
+
+    ckpt_setup(cfg, argv=sys.argv[1:] if argv is None else argv)
     device = torch.device(f"cuda:{cfg['runtime']['device_id'][0]}")
     torch.cuda.set_device(device)
     mano = load_mano(cfg, device)
@@ -128,12 +131,7 @@ def main(argv=None):
         _logger.info("unexpected_keys: %s", unexpected)
     else:
         _logger.warning("no --debug.model_weight_filepath: refining with randomly initialised weights")
-    if cfg["commit"]:
-        import yaml
-
-        os.makedirs(cfg["ckpt_path"], exist_ok=True)
-        with open(os.path.join(cfg["ckpt_path"], "opt.yml"), "w") as f:
-            yaml.safe_dump({k: v for k, v in cfg.items()}, f)
+    ckpt_opt(cfg)
     seen = set()
     n_written = 0
     for sample_id, clip in enumerate(clips):

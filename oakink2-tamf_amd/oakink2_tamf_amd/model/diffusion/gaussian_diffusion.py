@@ -4,9 +4,11 @@ variance), host side.
 Mirrors the call surface of the reference's model/diffusion/gaussian_diffusion.py for the branch sample.sh
 reaches (START_X / FIXED_SMALL / p_sample*, reference lines 116-161, 209-229, 231-320, 412-460, 506-640);
 DDIM / PLMS / VLB / training losses are out of scope.  The schedule stays float64
-numpy on the host exactly like the reference; the per-step arithmetic runs in the HIP library
-(hip_backend.TamfContext): fused into the output-head GEMM inside the hipGraph loop, or through tamf_ddpm_step
-on the generic path.
+numpy on the host exactly like the reference.  The launchers' call (clip_denoised=False, no denoised_fn / init_image /
+skip) takes the fused path: the whole loop is one library call, the per-step update fused into the output-head GEMM inside
+the hipGraph loop.  Any other combination takes the generic per-step path below: model.forward on the HIP library,
+q_posterior / p_sample in torch on the device, line for line as the reference (the standalone tamf_ddpm_step entry point
+of the C-ABI is the same update for callers without torch).
 """
 from __future__ import annotations
 

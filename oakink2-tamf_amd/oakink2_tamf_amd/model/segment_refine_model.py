@@ -8,8 +8,10 @@ manotorch / pytorch3d / chamfer_distance) are "next" rows (section 8f): either t
 batch["h2o_dist"] (B, T, 778), or it hands the module its MANO layers (`mano_layer_rh` / `mano_layer_lh`, any callable with
 manotorch's `layer(pose_coeffs=quat (T,16,4), betas=(T,10)) -> .verts (T,778,3), .joints (T,21,3)` contract; the MANO assets
 are licence-gated and not part of this package) and the module runs the reference's whole forward on the GPU: HIP pose decode
--> MANO -> HIP hand->object distance -> HIP trunk.  Vertex normals (:131-133) are not computed: they only enter the
-object->hand signed distance, which forward() discards (:165 keeps x2y, unsigned because y_normals is None).
+-> MANO -> HIP vertex normals -> HIP hand->object distance -> HIP trunk.  The vertex normals (:131-133, pytorch3d's
+verts_normals_packed) are computed when the MANO layer exposes its faces (`th_faces`, as manotorch's does) and returned in
+the result dict like the reference's; they do not enter the distance feature (:165 keeps x2y, unsigned because y_normals
+is None).
 """
 from __future__ import annotations
 
@@ -59,14 +61,21 @@ class SegmentRefineModel(_HipDenoiserBase):
         sd = {k: v for k, v in state_dict.items() if not k.startswith("mano_layer_")}
         return super().load_state_dict(sd, strict=strict, **kw)
 
-    # ---- reference :107-140 without the (unused) normals --------------------------------------------------------------
+    def retrieve_hand_faces(self, hand_side):
+        """reference :99-105: the triangle list of the side's MANO layer (None when the stand-in layer has no `th_faces`)"""
+        if hand_side not in ("rh", "lh"):
+            raise ValueError(f"unexpected hand_side: {hand_side}")
+        return getattr(self.mano_layer_rh if hand_side == "rh" else self.mano_layer_lh, "th_faces", None)
+
+    # ---- reference :107-140 ---------------------------------------------------------------------------------------------
     @torch.no_grad()
     def batch_recover_mano_from_pose_repr(self, batch_pose_repr, batch_shape, batch_hand_side):
-        """(B,T,99), (B,T,10), list of "rh"/"lh" -> hand_verts (B,T,778,3), hand_joints (B,T,21,3), wrist translation added"""
-        from ..geometry import pose_repr_to_quat
+        """(B,T,99), (B,T,10), list of "rh"/"lh" -> hand_verts (B,T,778,3), hand_joints (B,T,21,3) (wrist translation added),
+        hand_normals (B,T,778,3) or None when a layer does not expose its faces"""
+        from ..geometry import pose_repr_to_quat, vertex_normals
 
         tsl, quat = pose_repr_to_quat(batch_pose_repr)  # HIP: rot6d -> rotmat -> quaternion
-        verts, joints = [], []
+        verts, joints, normals = [], [], []
         for b, side in enumerate(batch_hand_side):
             if side not in ("rh", "lh"):
                 raise ValueError(f"unexpected hand_side: {side}")
@@ -76,7 +85,10 @@ class SegmentRefineModel(_HipDenoiserBase):
             out = layer(pose_coeffs=quat[b], betas=batch_shape[b].to(quat))
             verts.append(out.verts + tsl[b].unsqueeze(1))
             joints.append(out.joints + tsl[b].unsqueeze(1))
-        return torch.stack(verts, dim=0), torch.stack(joints, dim=0)
+            faces = self.retrieve_hand_faces(side)
+            normals.append(vertex_normals(verts[-1], faces) if faces is not None else None)  # HIP: :131-133
+        hand_normals = torch.stack(normals, dim=0) if all(n is not None for n in normals) else None
+        return torch.stack(verts, dim=0), torch.stack(joints, dim=0), hand_normals
 
     @staticmethod
     def _pad_object_points(obj_points_list, device):
@@ -114,9 +126,11 @@ class SegmentRefineModel(_HipDenoiserBase):
             h2o = batch["h2o_dist"]
         elif self.mano_layer_rh is not None or self.mano_layer_lh is not None:
             obj_pts = batch["obj_pointcloud"] if self.use_pc else batch["obj_verts"]
-            hv, hj = self.batch_recover_mano_from_pose_repr(x_in, batch["shape"], batch["hand_side"])
+            hv, hj, hn = self.batch_recover_mano_from_pose_repr(x_in, batch["shape"], batch["hand_side"])
             h2o = self.multi_object_h2o_dist(hv, batch["obj_list"], batch["obj_traj"], obj_pts)
             res["sample_hand_verts"], res["sample_hand_joints"] = hv, hj
+            if hn is not None:
+                res["sample_hand_normals"] = hn
         else:
             raise KeyError("batch['h2o_dist'] (B, T, 778) must be supplied, or the module built with mano_layer_rh / mano_layer_lh: "
                            "MANO FK is outside this package (SURVEY.md section 8f, row 1)")
@@ -126,7 +140,9 @@ class SegmentRefineModel(_HipDenoiserBase):
         out = ctx.refine(x_in, h2o)
         res["refine_pose_repr"], res["sample_h2o_dist"] = out, h2o
         if with_refined_geometry and "h2o_dist" not in batch:
-            rv, rj = self.batch_recover_mano_from_pose_repr(out, batch["shape"], batch["hand_side"])
+            rv, rj, rn = self.batch_recover_mano_from_pose_repr(out, batch["shape"], batch["hand_side"])
             res["refine_hand_verts"], res["refine_hand_joints"] = rv, rj
+            if rn is not None:
+                res["refine_hand_normals"] = rn
             res["refine_h2o_dist"] = self.multi_object_h2o_dist(rv, batch["obj_list"], batch["obj_traj"], obj_pts)
         return res

@@ -269,6 +269,24 @@ def capture_refine(name: str, arch: O.Arch, B: int, T: int, nobj=2):
     np.savez_compressed(os.path.join(OUT_DIR, f"refine_{name}.npz"), **fix)
 
 
+def capture_vertex_normals():
+    """Row 8(f)-1, vertex normals: pytorch3d is absent, so this fixture comes from the restatement of its published
+    algorithm (geometry_oracle.vertex_normals) - it pins the KERNEL on the oracle and the oracle on a file; the oracle
+    itself is pinned on analytic cases (tests/test_geometry.py)."""
+    from . import fixtures as FX
+    from . import geometry_oracle as G
+
+    v, f = FX.icosphere(2)
+    frames = []
+    for k in range(3):  # a breathing, sheared sphere: three "frames" of one topology
+        d = det.det_normal(f"vnormal/{k}", v.shape).astype(np.float32) * 0.03
+        frames.append((v * (1.0 + 0.1 * k) + d + np.array([0.1 * k, 0.0, 0.2], np.float32)).astype(np.float32))
+    verts = np.stack(frames)
+    normals = G.vertex_normals(verts, f)
+    np.savez_compressed(os.path.join(OUT_DIR, "vertex_normals.npz"), verts=verts, faces=f.astype(np.int32), normals=normals)
+    print("vertex_normals", verts.shape, f.shape)
+
+
 def capture_geometry():
     """Rows 8(f)-1/-2: the reference's own rot6d/quaternion helpers (dev_fn.transform) and its hand->object distance
     (SegmentRefineModel.multi_object_h2o_dist -> point2point_signed) with a stand-in `chamfer_distance` module that
@@ -430,6 +448,7 @@ def main():
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()
+    capture_vertex_normals()
     capture_contact()
     capture_collate()
     capture_siv()

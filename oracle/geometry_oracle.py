@@ -5,6 +5,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Citations relative to /root/
   pose_decode          99-d pose repr -> translation + 16 unit quaternions
                        (oakink2_tamf/launch/sample_refine.py:254-260, model/segment_refine_model.py:117-124;
                         dev_fn/transform/rotation.py:446-467 rot6d_to_rotmat, :167-213 rotmat_to_quat, :24-35, :156-164)
+  vertex_normals       hand-mesh vertex normals (model/segment_refine_model.py:131-133 -> pytorch3d 0.7.2, absent: restated
+                       from its published algorithm, pinned on analytic cases)
   h2o_dist             hand-vertex -> nearest object point distance feature of R
                        (oakink2_tamf/model/segment_refine_model.py:142-168 -> model/loss/chamfer_distance.py:4-64 with
                         y_normals=None: x2y_signed = || x - y[nearest] ||; dev_fn/transform/transform.py:148-154,36-52)
@@ -16,6 +18,7 @@ exactly that (oracle/capture_golden.py:capture_geometry), so the in-tree arithme
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 
@@ -161,3 +164,33 @@ def transform_points(obj_traj: torch.Tensor, obj_points: torch.Tensor) -> torch.
     obj_points (..., P, 3) -> (..., T, P, 3) = R p + t per frame."""
     R = rot6d_to_rotmat(obj_traj[..., 3:9])  # (..., T, 3, 3), rows b1, b2, b3
     return torch.einsum("...tij,...pj->...tpi", R, obj_points) + obj_traj[..., None, 0:3]
+
+
+def vertex_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Vertex normals as the reference obtains them (model/segment_refine_model.py:131-133):
+    pytorch3d.structures.Meshes(verts, faces).verts_normals_packed().  pytorch3d (pinned 0.7.2, requirements.dist.txt:331) is
+    absent here; this restates its published algorithm (structures/meshes.py, Meshes._compute_vertex_normals):
+
+        vertices_faces = verts[faces]                                    # (F, 3, 3)
+        n.index_add(0, faces[:, 1], cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1]))
+        n.index_add(0, faces[:, 2], cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2]))
+        n.index_add(0, faces[:, 0], cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0]))
+        n = torch.nn.functional.normalize(n, eps=1e-6, dim=1)            # x / max(|x|, eps)
+
+    verts (..., V, 3) float32, faces (F, 3) -> (..., V, 3) float32, accumulated sequentially in float32 (np.add.at = the CPU
+    index_add_ order).  Parity of this row is pinned on the definition (analytic cases in tests), not on pytorch3d itself."""
+    v = np.asarray(verts, dtype=np.float32)
+    f = np.asarray(faces, dtype=np.int64)
+    lead = v.shape[:-2]
+    vv = v.reshape((-1,) + v.shape[-2:])
+    out = np.zeros_like(vv)
+    for m in range(vv.shape[0]):
+        x = vv[m]
+        vf = x[f]
+        n = np.zeros_like(x)
+        np.add.at(n, f[:, 1], np.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1]).astype(np.float32))
+        np.add.at(n, f[:, 2], np.cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2]).astype(np.float32))
+        np.add.at(n, f[:, 0], np.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0]).astype(np.float32))
+        ln = np.sqrt((n.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
+        out[m] = n / np.maximum(ln, np.float32(1e-6))[:, None]
+    return out.reshape(lead + v.shape[-2:])

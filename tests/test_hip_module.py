@@ -137,6 +137,9 @@ def test_refine_forward_with_mano_layers():
             w = (Wq.to(pose_coeffs) * sign, Wb.to(pose_coeffs))
             v = (pose_coeffs.reshape(pose_coeffs.shape[0], 64) @ w[0] + betas @ w[1]).reshape(-1, 778, 3)
             return SimpleNamespace(verts=v, joints=v[:, :21])
+        from oracle.fixtures import icosphere
+
+        layer.th_faces = torch.from_numpy(icosphere(3)[1].astype(np.int64))  # a closed 642-vertex topology on the first vertices
         return layer
 
     m = SegmentRefineModel(None, latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers,
@@ -161,6 +164,11 @@ def test_refine_forward_with_mano_layers():
     hv = torch.stack([fake_mano(1.0 if s == "rh" else -1.0)(quat[b], torch.from_numpy(fix["cond/shape"][b])).verts
                       + x_in[b, :, None, 0:3] for b, s in enumerate(sides)])
     np.testing.assert_allclose(res["sample_hand_verts"].cpu().numpy(), hv.numpy(), rtol=0, atol=5e-6)
+    # vertex normals of the hand mesh (reference :131-133): the kernel on the module's own vertices against the oracle
+    faces = fake_mano(1.0).th_faces.numpy()
+    n_ref = G.vertex_normals(res["sample_hand_verts"].cpu().numpy(), faces)
+    np.testing.assert_allclose(res["sample_hand_normals"].cpu().numpy(), n_ref, rtol=0, atol=2e-6)
+    assert res["refine_hand_normals"].shape == (B, T, 778, 3)
     pts = torch.zeros(B, nobj, 300, 3)
     for b, c in enumerate(clouds):
         pts[b, : c.shape[0]] = torch.from_numpy(c)
@@ -221,8 +229,8 @@ def test_cli_synthetic_end_to_end(tmp_path, monkeypatch):
 
     monkeypatch.chdir(tmp_path)
     rc = S.main(["--cfg", os.path.join(ROOT, "config", "arch_mdm.yml"), "--model.num_layers", "2", "--synthetic", "3,16",
-                 "--debug.sample_save_offset", "test/run0", "--runtime.device_id", "0", "--runtime.batch_size", "2",
-                 "--diffusion_steps", "5", "--commit"])
+                 "--debug.sample_save_offset", "test/run0", "--runtime.device_id", "0", "--runtime.num_worker", "1",
+                 "--runtime.batch_size", "2", "--diffusion_steps", "5", "--commit"])
     assert rc == 0
     d = tmp_path / "common" / "sample" / "main" / "sample" / "test" / "run0"
     files = sorted(os.listdir(d))
@@ -230,3 +238,49 @@ def test_cli_synthetic_end_to_end(tmp_path, monkeypatch):
     a = np.load(d / "000002.npy")
     assert a.shape == (16, 99) and a.dtype == np.float32 and np.isfinite(a).all()
     assert (tmp_path / "common" / "sample" / "main" / "opt.yml").exists()
+    assert "commit mode: setup ckpt" in (tmp_path / "common" / "sample" / "main" / "log.txt").read_text()
+
+
+def test_cli_loads_a_saved_checkpoint(tmp_path, monkeypatch):
+    """--debug.model_weight_filepath: a torch.save'd state dict in the reference's format (flat keys, no clip_model.*,
+    launch/sample.py:190-192 loads it with strict=False) goes through the launcher; the written samples equal the fused
+    loop of a module that was handed the same weights directly (same seed, same global clip ids)."""
+    import os
+
+    from conftest import ROOT
+    from oakink2_tamf_amd.launch import sample as S
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+    from oracle import mdm_oracle as O
+
+    monkeypatch.chdir(tmp_path)
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="ckpt/w")
+    ck = dict(sd)
+    ck["some.unexpected.key"] = torch.zeros(3)  # strict=False: reported, ignored
+    torch.save(ck, tmp_path / "model.pt")
+    B, T, N = 3, 16, 4
+    rng = np.random.default_rng(1)
+    cond = {"text_embedding": rng.standard_normal((B, 512)).astype(np.float32), "hand_side": np.array(["rh", "lh", "rh"]),
+            "shape": np.repeat(rng.standard_normal((B, 1, 10)).astype(np.float32), T, axis=1),
+            "obj_embedding": rng.standard_normal((B, 2, 768)).astype(np.float32),
+            "obj_traj": rng.standard_normal((B, 2, T, 9)).astype(np.float32)}
+    np.savez(tmp_path / "cond.npz", **cond)
+    args = ["--model.latent_dim", str(arch.latent_dim), "--model.ff_size", str(arch.ff_size), "--model.num_layers", str(arch.num_layers),
+            "--model.num_heads", str(arch.num_heads), "--data.cond_npz", str(tmp_path / "cond.npz"), "--debug.model_weight_filepath",
+            str(tmp_path / "model.pt"), "--debug.sample_save_offset", "test/ckpt", "--runtime.device_id", "0", "--runtime.num_worker", "1",
+            "--diffusion_steps", str(N), "--precision", "f32", "--seed", "5", "--commit"]
+    assert S.main(args) == 0
+    d = tmp_path / "common" / "sample" / "main" / "sample" / "test" / "ckpt"
+    got = np.stack([np.load(d / f"{i:06d}.npy") for i in range(B)])  # (B, T, 99)
+    m = _module(arch, sd, "f32")
+    batch = {"text_embedding": torch.from_numpy(cond["text_embedding"]).cuda(), "hand_side": ["rh", "lh", "rh"],
+             "shape": torch.from_numpy(cond["shape"]).cuda(), "obj_embedding": torch.from_numpy(cond["obj_embedding"]).cuda(),
+             "obj_traj": torch.from_numpy(cond["obj_traj"]).cuda()}
+    ref = create_gaussian_diffusion(N, "cosine").p_sample_loop(m, (B, 99, 1, T), clip_denoised=False, model_kwargs={"batch": batch},
+                                                               seed=5, clip_id_base=0)
+    np.testing.assert_array_equal(got, ref.permute(0, 3, 1, 2).squeeze(3).cpu().numpy())
+    # and against the oracle with the same Philox draws
+    tab = O.make_tables(N, "cosine")
+    ocond = {k: (torch.from_numpy(v) if k != "hand_side" else list(v)) for k, v in cond.items()}
+    oref = O.sample_loop(sd, arch, tab, ocond, (B, 99, 1, T), lambda k: torch.from_numpy(O.philox_normal(5, np.arange(B), k, 99, T)))
+    assert np.abs(got - oref.permute(0, 3, 1, 2).squeeze(3).numpy()).max() < 2e-4

@@ -162,3 +162,56 @@ def test_refine_oracle_matches_reference():
                 "obj_traj": torch.from_numpy(fix["cond/obj_traj"])}
         out = O.refine_forward(sd, arch, torch.from_numpy(fix["x_in"]), torch.from_numpy(fix["h2o"]), cond)
         np.testing.assert_allclose(out.numpy(), fix["out"], rtol=0, atol=1e-5)
+
+
+def test_file_macro_and_process_range(tmp_path):
+    """`?(file:<path>)` list entries expand to the file's stripped lines, missing files to nothing, duplicates are dropped
+    keeping first occurrences (reference dev_fn/upkeep/config.py:26-72); --data.process_range selects the clips of a
+    conditioning file by their process keys (reference launch/sample.py:161-166 walks the dataset by them)."""
+    from oakink2_tamf_amd.launch import sample as S
+    from oakink2_tamf_amd.launch.upkeep import decode_file_macro
+
+    lst = tmp_path / "keys.txt"
+    lst.write_text("  scene_b  \nscene_c\nscene_a\n")
+    assert decode_file_macro(["scene_a", f"?(file:{lst})", "?(file:/nonexistent/x.txt)", "scene_d", "?(other:cmd)"]) == [
+        "scene_a", "scene_b", "scene_c", "scene_d"]
+    assert decode_file_macro(None) is None
+    B, T = 5, 8
+    rng = np.random.default_rng(0)
+    npz = tmp_path / "cond.npz"
+    np.savez(npz, text_embedding=rng.standard_normal((B, 512)).astype(np.float32), hand_side=np.array(["rh", "lh", "rh", "lh", "rh"]),
+             shape=rng.standard_normal((B, T, 10)).astype(np.float32), obj_embedding=rng.standard_normal((B, 2, 768)).astype(np.float32),
+             obj_traj=rng.standard_normal((B, 2, T, 9)).astype(np.float32),
+             process_key=np.array(["scene_a", "scene_x", "scene_c", "scene_y", "scene_b"]))
+    known, dotted = S.parse_args(["--data.cond_npz", str(npz), "--data.process_range", f"scene_c,?(file:{lst})"])
+    cfg = S.build_config(known, dotted)
+    assert cfg["data"]["process_range"] == ["scene_c", "scene_b", "scene_a"]
+    cond = S.load_conditioning(cfg, known)
+    assert cond["shape"].shape[0] == 3 and list(cond["hand_side"]) == ["rh", "rh", "rh"]  # clips 0, 2, 4 in file order
+    assert cfg["runtime"]["num_worker"] == 8 and cfg["runtime"]["device_id"] == [0, 1, 2, 3]  # the reference's defaults
+
+
+def test_ckpt_setup_log_file(tmp_path, monkeypatch):
+    """commit mode creates common/<prog>/<exp_id>/ with log.txt and opt.yml; a dry run writes nothing (upkeep/ckpt.py:110-149)"""
+    import logging
+
+    from oakink2_tamf_amd.launch import sample as S
+    from oakink2_tamf_amd.launch.upkeep import ckpt_opt, ckpt_setup
+
+    monkeypatch.chdir(tmp_path)
+    cfg = S.build_config(*S.parse_args(["--synthetic", "2,8", "--exp_id", "e1"]))
+    ckpt_setup(cfg, argv=["--synthetic", "2,8"])
+    ckpt_opt(cfg)
+    assert not os.path.exists(tmp_path / "common")
+    cfg = S.build_config(*S.parse_args(["--synthetic", "2,8", "--exp_id", "e1", "--commit"]))
+    logging.getLogger().setLevel(logging.INFO)
+    ckpt_setup(cfg, argv=["--synthetic", "2,8", "--commit"])
+    ckpt_opt(cfg)
+    for h in list(logging.getLogger().handlers):
+        if isinstance(h, logging.FileHandler):
+            h.flush()
+            logging.getLogger().removeHandler(h)
+    d = tmp_path / "common" / "sample" / "e1"
+    text = (d / "log.txt").read_text()
+    assert "commit mode: setup ckpt" in text and "cmd:" in text and "--synthetic 2,8" in text
+    assert (d / "opt.yml").exists()
