@@ -200,7 +200,7 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // 5-8 %).  Only the kernel benchmark hook (tamf_bench_gemm) overrides it.
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
-// 2 = FFN2 on the 128 x 128 tiles, 8 = FFN1 on the 128 x 128 tiles
+// 2 = FFN2 on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -213,7 +213,7 @@ struct GemmLaunch {
   // wave grid: the 64-row LayerNorm tiles own a CU and run 8 waves (2 x 4), the 64 x 512 one 16 waves (2 x 8: four waves
   // per SIMD cover each other's LDS / barrier latency, 36.6 -> 35.1 us for out-proj); the 128 x 128 tiles run 4 waves
   // (2 x 2) with two workgroups per CU
-  static constexpr int WGN = (BM == 64) ? (BN == 512 ? 8 : 4) : 2;
+  static constexpr int WGN = (BM <= 64) ? (BN == 512 ? 8 : 4) : 2;
   template <int SPLIT>
   static hipError_t prepare1() {
     return hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, WGN, Epi, SPLIT>,
@@ -238,7 +238,7 @@ struct GemmLaunch {
     if ((ga.K * Op::EB) % GEMM_BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
     const int ntn = ga.N / BN, ntm = (ga.M + BM - 1) / BM, tiles = ntn * ntm;
     GemmArgs<Op> gb = ga;
-    gb.krot = krot_for(BM == 64);
+    gb.krot = krot_for(BM <= 64 && BN >= 256);
     // wide-N launches (FFN1: 16 column tiles): XCDs in a 4 x 2 arrangement over the tile grid - each L2 then serves half of W
     // instead of all of it (FETCH_SIZE 162 -> 137 MB per launch, time unchanged); with few column tiles it would re-read A
     if (g_krot < 0 && BM == 128 && ntn >= 8) gb.krot |= 0x10000;
@@ -316,8 +316,22 @@ struct ClipLaunch {
   }
 };
 
+// share of the workgroup slots of its rounds that a launch of `tiles` workgroups uses
+static inline double round_util(int tiles, int slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
+
+// 128 x 128 tiles, or 64 x 128 tiles (8 waves) for the short-K launches that fill at most half of the workgroup slots (the
+// input-merge GEMMs at <= 32 clips: 20.7 against 23.4 us at B = 32).  Measured and left on the big tiles: QKV (624 tiles at
+// B = 32: 43 against 37 us) and FFN2 (K = 2048: 58 against 56 us).
+template <class Epi> struct EpiHasSmallTile { static constexpr bool value = false; };
+template <class Op> struct EpiHasSmallTile<EpiBiasAct<Op>> { static constexpr bool value = true; };
+template <class Op> struct EpiHasSmallTile<EpiSeqRows<Op>> { static constexpr bool value = true; };
 template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+  if constexpr (EpiHasSmallTile<Epi>::value) {
+    const int t128 = ((ga.M + 127) / 128) * (ga.N / 128);
+    if (!(g_sel & 1) && ga.N % 128 == 0 && t128 * 2 <= g_wg_slots && ga.K * Op::EB <= 2048)
+      return GemmLaunch<Op, 64, 128, Epi>::launch(ga, epi, st);
+  }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
 template <class Op>
@@ -325,7 +339,10 @@ static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStrea
   switch (ga.N) {
     case 128: return GemmLaunch<Op, 64, 128, EpiLN<Op>>::launch(ga, epi, st);
     case 256: return GemmLaunch<Op, 64, 256, EpiLN<Op>>::launch(ga, epi, st);
-    case 512: return GemmLaunch<Op, 64, 512, EpiLN<Op>>::launch(ga, epi, st);
+    case 512:
+      // fewer 64-row blocks than 60 % of the CUs (B = 32: 104): 32-row blocks
+      if (!(g_sel & 1) && ((ga.M + 63) / 64) * 10 < (g_wg_slots / 2) * 6) return GemmLaunch<Op, 32, 512, EpiLN<Op>>::launch(ga, epi, st);
+      return GemmLaunch<Op, 64, 512, EpiLN<Op>>::launch(ga, epi, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -340,6 +357,9 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 32, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
@@ -358,6 +378,7 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
   // fewer (clip, head) pairs than CUs (B = 32: 128): split the queries of a pair over workgroups until the chip is filled;
   // K/V are then streamed once per workgroup, which costs less than idle CUs (a query's result does not depend on the split)
   while (chunks * B * aa.H < g_wg_slots / 2 && chunks * 2 <= nqt) chunks *= 2;
+  if ((g_sel & 4) && chunks * 2 <= nqt) chunks *= 2;  // A/B: one more split (two workgroups per CU at B = 64)
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
   constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;

@@ -7,7 +7,9 @@ from conftest import golden_cond, load_golden
 from oracle import det, mdm_oracle as O
 from test_hip_forward import _make_ctx, _set_cond
 
-for prec in ("f32", "bf16x3", "bf16"):
+import subprocess
+print("commit", subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or os.environ.get("TAMF_COMMIT", "(snapshot without .git: see the file name / commit message)"))
+for prec in ("f32", "f16x3", "bf16x3", "bf16"):
     for name, arch in (("tiny", O.ARCH_TINY), ("arch_mdm", O.ARCH_MDM), ("arch_mdm_l", O.ARCH_MDM_L), ("arch_mdm_l_t196", O.ARCH_MDM_L)):
         fix = load_golden(f"forward_{name}.npz"); sd = O.det_state_dict(arch, tag=f"{name}/w")
         x = torch.from_numpy(fix["x"]); B, _, _, T = x.shape

@@ -6,7 +6,7 @@
 #   bench_default.log              the default bench line
 export TMPDIR=/tmp
 out=gpurun_out/prof; rm -rf $out; mkdir -p $out
-for dt in ${1:-bf16x3 bf16}; do
+for dt in ${1:-f16x3 f32 bf16 bf16x3}; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$dt -o r -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 100 --no-cpu-baseline --also "" --dtype $dt > $out/ks_$dt.log 2>&1
   python3 - $out $dt <<'PY'
 import csv, glob, sys
@@ -26,7 +26,7 @@ PY
   python3 - $out $dt <<'PY'
 import csv, glob, json, sys, collections
 out, dt = sys.argv[1:3]
-CLASSES = [("EpiQKV", "gemm_qkv"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),
+CLASSES = [("EpiQKV", "gemm_qkv"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
            ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
 def per_launch(ctr):
     f = glob.glob(f"{out}/pmc_{dt}_{ctr}/**/*counter_collection.csv", recursive=True)
@@ -41,7 +41,7 @@ def per_launch(ctr):
 fe, wr = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
 kern = {}
 for k in sorted(set(fe) | set(wr)):
-    name = "gemm_outproj_ln" if (k == "gemm_ln" and dt == "bf16x3") else k
+    name = "gemm_outproj_ln" if (k == "gemm_ln" and dt in ("bf16x3", "f16x3")) else k  # split modes: FFN2 runs as gemm_ffn2 + ffn2_residual_ln
     f_b, w_b = fe.get(k, 0.0) * 1024.0 * 2.0, wr.get(k, 0.0) * 1024.0
     kern[name] = {"fetch_bytes_corrected": f_b, "write_bytes": w_b, "traffic_bytes_per_launch": f_b + w_b}
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also '' --dtype " + dt,
