@@ -176,6 +176,10 @@ int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_
 
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);
+/* hipGraph bookkeeping of the sampling loop: how often a step sequence has been captured + instantiated on this context
+ * (once per (B, T, n_steps): seeds, clip ranges and noise tensors replay the same executable graph) and how many graph
+ * launches the last tamf_sample_loop call made (n_steps / steps per graph).  Either pointer may be NULL. */
+int tamf_loop_stats(const tamf_ctx* ctx, int32_t* graph_captures, int32_t* graph_launches_last_loop);
 /* Runs ONE denoiser step (DDPM update at t = n_steps/2, Philox noise; the sampler state is advanced by it) kernel by
  * kernel with hipEvents recorded on `stream` after every launch, synchronises, and reports per launch: elapsed
  * milliseconds, the algorithmic FLOPs of the reference work it stands for, and a name

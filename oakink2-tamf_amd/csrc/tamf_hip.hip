@@ -98,6 +98,7 @@ struct tamf_ctx {
   bool graph_in_flight = false;
   LoopParams* loop_params = nullptr;
   int sched_cap = 0;  // allocated length of c1 / c2 / sigma
+  int graph_captures = 0, graph_launches_last_loop = 0;  // tamf_loop_stats
   int step_kernels = 0;
   // per-launch profiling (tamf_step_profile)
   bool prof_on = false;
@@ -1012,8 +1013,10 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
       HIPCHK(ctx, ee);
       HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
       ctx->graph_key = key;
+      ++ctx->graph_captures;
     }
     for (int i = 0; i < N / G; ++i) HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+    ctx->graph_launches_last_loop = N / G;
     HIPCHK(ctx, hipEventRecord(ctx->graph_done, st));
     ctx->graph_in_flight = true;
   }
@@ -1036,6 +1039,13 @@ extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t 
 }
 
 extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
+
+extern "C" int tamf_loop_stats(const tamf_ctx* ctx, int32_t* graph_captures, int32_t* graph_launches_last_loop) {
+  if (!ctx) return TAMF_ERR_INVALID;
+  if (graph_captures) *graph_captures = ctx->graph_captures;
+  if (graph_launches_last_loop) *graph_launches_last_loop = ctx->graph_launches_last_loop;
+  return 0;
+}
 
 template <class Op>
 static int profile_impl(tamf_ctx* ctx, hipStream_t st) {

@@ -55,6 +55,7 @@ def lib() -> ctypes.CDLL:
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
         L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_step_kernel_count.argtypes = [c_void_p]
+        L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
         L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
         L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
@@ -259,6 +260,12 @@ class TamfContext:
             _check(lib().tamf_refine(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()),
                                      c_void_p(_stream_ptr(dev))), self._h)
         return out
+
+    def loop_stats(self):
+        """(graph captures so far, graph launches of the last sample_loop call)"""
+        a, b = c_int32(), c_int32()
+        _check(lib().tamf_loop_stats(self._h, ctypes.byref(a), ctypes.byref(b)), self._h)
+        return int(a.value), int(b.value)
 
     @property
     def step_kernel_count(self) -> int:

@@ -141,3 +141,36 @@ def test_clip_sample_independent_of_batch_size_and_position(prec):
     two = ctx.sample_loop(noise=None, seed=11, clip_id_base=101).cpu()
     assert torch.equal(two, full[1:3])
     ctx.close()
+
+
+def test_graph_is_captured_once_per_shape_and_spans_several_steps():
+    """The loop graph holds the largest divisor of N up to 16 steps and is step-, seed-, clip-range- and noise-agnostic:
+    new seeds / clip bases / supplied-noise tensors replay the same executable graph; only a new (B, T, N) re-captures."""
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="rob/w")
+    ctx = _ctx(arch, sd, 3, 16, "f32", n_steps=1000)
+    _set_cond(ctx, _cond(3, 16, "graph"))
+    outs = [ctx.sample_loop(noise=None, seed=s, clip_id_base=b).cpu() for s, b in ((1, 0), (2, 0), (2, 7))]
+    assert ctx.loop_stats() == (1, 100)  # one capture, 1000 / 10 launches per loop
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    again = ctx.sample_loop(noise=None, seed=1, clip_id_base=0).cpu()
+    assert torch.equal(again, outs[0]) and ctx.loop_stats() == (1, 100)
+    ctx.close()
+    # step counts without a divisor in 2..16 fall back to one step per graph; N = 12 is one 12-step graph
+    for N, launches in ((17, 17), (12, 1), (34, 17)):
+        ctx = _ctx(arch, sd, 2, 16, "f32", n_steps=N)
+        cond = _cond(2, 16, "graph")
+        _set_cond(ctx, cond)
+        g = torch.Generator().manual_seed(N)
+        draws = torch.randn(N + 1, 2, 99, 1, 16, generator=g)
+        out = ctx.sample_loop(noise=draws).cpu()
+        ref = O.sample_loop(sd, arch, O.make_tables(N, "cosine"), cond, (2, 99, 1, 16), lambda k: draws[k])
+        assert float((out - ref).abs().max()) < 1e-5, N
+        assert ctx.loop_stats() == (1, launches), (N, ctx.loop_stats())
+        # supplied noise of another loop: same graph
+        out2 = ctx.sample_loop(noise=draws.flip(1).contiguous()).cpu()
+        assert ctx.loop_stats()[0] == 1 and not torch.equal(out, out2)
+        ctx.close()

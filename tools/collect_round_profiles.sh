@@ -28,20 +28,26 @@ import csv, glob, json, sys, collections
 out, dt = sys.argv[1:3]
 CLASSES = [("EpiQKV", "gemm_qkv"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
            ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
+SPLIT = dt in ("bf16x3", "f16x3")  # split modes: every EpiLN launch is the out-proj; the others alternate out-proj / FFN2 per layer
 def per_launch(ctr):
     f = glob.glob(f"{out}/pmc_{dt}_{ctr}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(f[0])):
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
+    ln_seen = {}
+    for r in rows:
         for pat, name in CLASSES:
             if pat in r["Kernel_Name"]:
+                if name == "gemm_ln":
+                    if r["Dispatch_Id"] not in ln_seen:
+                        ln_seen[r["Dispatch_Id"]] = len(ln_seen)
+                    name = "gemm_outproj_ln" if (SPLIT or ln_seen[r["Dispatch_Id"]] % 2 == 0) else "gemm_ffn2_ln"
                 acc[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
                 break
-    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of ... rocprofv3 reports them in KB per the guide: bytes = value * 1024? keep raw and note
     return {k: sorted(v.values())[len(v) // 2] for k, v in acc.items()}  # median over launches (merge0's BiasAct launch is the minority)
 fe, wr = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE")
 kern = {}
 for k in sorted(set(fe) | set(wr)):
-    name = "gemm_outproj_ln" if (k == "gemm_ln" and dt in ("bf16x3", "f16x3")) else k  # split modes: FFN2 runs as gemm_ffn2 + ffn2_residual_ln
+    name = k
     f_b, w_b = fe.get(k, 0.0) * 1024.0 * 2.0, wr.get(k, 0.0) * 1024.0
     kern[name] = {"fetch_bytes_corrected": f_b, "write_bytes": w_b, "traffic_bytes_per_launch": f_b + w_b}
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also '' --dtype " + dt,
