@@ -201,7 +201,8 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // 5-8 %).  Only the kernel benchmark hook (tamf_bench_gemm) overrides it.
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
-// 2 = FFN2 on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles
+// 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
+// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -791,6 +792,17 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
 // ------------------------------------------------------------------------------------------------
 // one denoiser evaluation = the kernel sequence below (captured into a hipGraph by the sampling loop)
 // ------------------------------------------------------------------------------------------------
+// second kernel of the two-kernel form of a LayerNorm-fused GEMM: X = LayerNorm(tmp32 + X) (+ operand)
+template <class Op>
+static void launch_residual_ln(tamf_ctx* ctx, const float* gamma, const float* beta, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  const int M = ctx->M, d = ctx->d, rows_per_blk = 4;
+  dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
+  if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+  else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+  else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+}
+
 template <class Op>
 static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_in) {
   typedef typename Op::elem_t E;
@@ -843,9 +855,18 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
-      EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f};
-      HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
-      mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
+      // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes keep the fused 64 x d tile (40 against 25 + 17 us)
+      if ((Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32 && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, d)) {
+        EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE};
+        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
+        mark("gemm_outproj", BS * 2.0 * dd * dd);
+        launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
+        mark("outproj_residual_ln", 0.0);
+      } else {
+        EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f};
+        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+        mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
+      }
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
@@ -858,8 +879,12 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      const bool clip2 = Op::SPLIT && !(g_sel & 2) && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
-      if (Op::SPLIT && ctx->tmp32) {
+      // GEMM + row-wise LayerNorm kernel: always in the split modes (the 64 x d LayerNorm tile streams the whole 4 MB weight panel
+      // through every CU), and in f32 when the clip tiles apply (64 x 512 f32 tiles reach 75 TFLOP/s, the clip tiles 113: 362 ->
+      // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
+      // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
+      const bool clip2 = (Op::SPLIT || Op::PREC == 0) && !(g_sel & 2) && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
+      if ((Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
         if (clip2)
@@ -867,11 +892,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         else
           HIPCHK(ctx, gemm128<Op>(ga, ep, st));
         mark("gemm_ffn2", BS * 2.0 * dd * ff);
-        const int rows_per_blk = 4;
-        dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
-        if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
-        else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
-        else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+        launch_residual_ln<Op>(ctx, w.g2, w.be2, st);
         mark("ffn2_residual_ln", 0.0);
       } else {
         EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f};
@@ -1391,7 +1412,7 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..23: kernel-selection overrides
-  g_sel = krot >= 0 ? (krot >> 20) & 0xF : 0;
+  g_sel = krot >= 0 ? (krot >> 20) & 0xFF : 0;
   g_krot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
   return 0;
 }
