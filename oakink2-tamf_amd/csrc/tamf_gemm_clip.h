@@ -14,8 +14,8 @@
 //
 // Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 ("X") own the first
 // XSUB row tiles, waves 4-7 ("Y") the other 13 - XSUB (waves w and w + 4 share a SIMD, so every SIMD carries all 13), each
-// over BN / 4 columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA pieces of
-// 8 rows x 128 bytes, source-side XOR swizzle, double-buffered stages, one barrier per K tile).
+// over BN / 4 columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA
+// pieces of 8 rows x 128 bytes, source-side XOR swizzle, double-buffered stages, one barrier per K tile).
 //
 // The two waves of a SIMD run half a K tile apart.  Right after a barrier every wave would wait for its first fragments
 // (LDS latency) and then issue its share of the next K tile's 58 LDS-DMA pieces (the CU's address unit takes 16 cycles per
@@ -26,7 +26,10 @@
 // K tile i, all DMA pieces of K tile i + 1, MFMAs of K tile i - while their SIMD partners ("Y": waves 4-7) spend the head of
 // the interval on the MFMAs of K tile i - 1, whose fragments they read into registers at the end of the previous interval,
 // and its tail on reading the fragments of K tile i.  The matrix pipe of every SIMD is fed by Y while X waits and issues, and
-// by X while Y reads; Y's fragments (its 6 row tiles + the column tiles: 80 registers) fit because Y owns one row tile less.
+// by X while Y reads.  Y issues its MFMAs at static priority and X, which carries the DMA issue, owns fewer of the 13 row
+// tiles (XSUB = 6 at 256 columns - 5 : 8 would spill Y's fragment registers - and 4 at 128 columns).  Per-wave shader-clock
+// stamps (tools/clip_timeline.py, -DTAMF_TIMELINE) at 256 columns: the matrix pipe is busy 2 744 of the 3 020 cycles of a
+// K-tile interval (156 MFMAs at 17.6 cycles), the loads are hidden completely.
 //
 // Workgroups are persistent over their tiles.  The accumulators are parked in LDS in slabs of 64 rows and handed to the same
 // row-wise epilogue functors as the other GEMMs (their stores drain behind the next slab and the next tile's first K tiles).

@@ -14,7 +14,7 @@ cond = O.det_cond(B, T, tag="bench_r/c", arch=arch)
 x_in = torch.from_numpy(det.det_normal("bench_r/x", (B, T, 99))).cuda()
 h2o = (torch.from_numpy(det.det_normal("bench_r/h", (B, T, 778))) * 0.05).cuda()
 res = {}
-for prec in ("bf16x3", "bf16", "f32"):
+for prec in ("f16x3", "bf16x3", "bf16", "f32"):
     ctx = TamfContext(dict(latent_dim=256, ff_size=1024, num_layers=8, num_heads=4), B, T, precision=prec, kind="R")
     ctx.load_state_dict(sd)
     ctx.set_cond(None, cond["hand_side"], cond["shape"].cuda(), cond["obj_embedding"].cuda(), cond["obj_traj"].cuda())
