@@ -48,7 +48,11 @@ TAMF_DEV uint32_t pack_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tamf_bf16x2));
 }
 // bf16x3 split of a pair: hi = bf16(v), lo = bf16(v - hi); both packed, element 0 in the low half (6 VALU per pair)
+// (fp contract off, here and in the other splits: the subtraction must not fuse with a multiply that produced `a` in the
+// caller - whether it does depends on the code around the call, and two kernel variants would then store different lo
+// words for the same value: the batch-invariance tests compare them bit for bit)
 TAMF_DEV void split_bf16x3(float a, float b, uint32_t& hi, uint32_t& lo) {
+#pragma clang fp contract(off)
   hi = pack_bf16(a, b);
   lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u));
 }
@@ -60,6 +64,7 @@ TAMF_DEV uint32_t pack_f16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tamf_f16x2));
 }
 TAMF_DEV void split_f16x3(float a, float b, uint32_t& hi, uint32_t& lo) {
+#pragma clang fp contract(off)
   hi = pack_f16(a, b);
   const tamf_f16x2 h = __builtin_bit_cast(tamf_f16x2, hi);
   lo = pack_f16(a - (float)h[0], b - (float)h[1]);
@@ -226,6 +231,7 @@ struct OpBF16X3 {
     store_bf16_vec<N>(p + 64, wl);
   }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
+#pragma clang fp contract(off)
     char* p = (char*)base + byte_off(idx);
     const uint32_t hi = f2bf(v);
     *(uint16_t*)p = (uint16_t)hi;
@@ -267,6 +273,7 @@ struct OpF16X3 {
     store_bf16_vec<N>(p + 64, wl);
   }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
+#pragma clang fp contract(off)
     char* p = (char*)base + byte_off(idx);
     const _Float16 hi = (_Float16)v;
     *(_Float16*)p = hi;

@@ -62,6 +62,15 @@ TAMF_DEV void g_load8(const float* p, float (&v)[8]) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
   v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+template <int N>
+TAMF_DEV void g_loadn(const float* p, float (&v)[N]) {
+  static_assert(N % 4 == 0, "16-byte loads");
+#pragma unroll
+  for (int j = 0; j < N; j += 4) {
+    const float4 a = *(const float4*)(p + j);
+    v[j] = a.x; v[j + 1] = a.y; v[j + 2] = a.z; v[j + 3] = a.w;
+  }
+}
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
   gst16f(p, v[0], v[1], v[2], v[3]);
   gst16f(p + 4, v[4], v[5], v[6], v[7]);
@@ -111,33 +120,48 @@ struct EpiBiasAct {
       if (gr >= M) break;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += cc.bi[j];
-      if (rowadd) {
-        float b[8];
-        g_load8(rowadd + (long)gr * ld_rowadd + gn, b);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
-      }
-      if (act == ACT_SILU) {
-        if constexpr (OutOp::PREC == 0) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = silu_fast(v[j]);
-        }
-      } else if (act == ACT_GELU) {
-        if constexpr (OutOp::PREC == 0) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
-        }
-      }
-      OutOp::template store<8>(out, (long)gr * ldo + gn, v);
+      finish_act<8>(act, gr, gn, v, cc.bi);
     }
+  }
+  // bias, row term, activation and operand store of N (4 or 8) consecutive columns gn .. of row gr: shared by the LDS-walking
+  // form above and the register form of tamf_gemm_clip.h, so both produce the same bits.  `a` = this->act (the register form
+  // passes it as a literal per branch, so that its unrolled row tiles carry one activation)
+  template <int N>
+  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += bi[j];
+    if (rowadd) {
+      float b[N];
+      g_loadn<N>(rowadd + (long)gr * ld_rowadd + gn, b);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] += b[j];
+    }
+    if (a == ACT_SILU) {
+      if constexpr (OutOp::PREC == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = silu_exact(v[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = silu_fast(v[j]);
+      }
+    } else if (a == ACT_GELU) {
+      if constexpr (OutOp::PREC == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = gelu_erf(v[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = gelu_erf_fast(v[j]);
+      }
+    }
+    OutOp::template store<N>(out, (long)gr * ldo + gn, v);
+  }
+  // register form: a lane stores 16 bytes per instruction - 4 columns of a 4-byte output, 8 of a 16-bit plane
+  static constexpr int LANE_CHUNK = OutOp::PREC == 0 ? 4 : 8;
+  template <int N>
+  TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) bi[j] = 0.f;
+    if (bias) g_loadn<N>(bias + gn, bi);
   }
 };
 
@@ -460,17 +484,30 @@ struct EpiStoreF32 {
       if (gr >= M) break;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += cc.bi[j];
-      if (act == ACT_SILU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_exact(v[j]);
-      } else if (act == ACT_GELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-      }
-      g_store8(out + (long)gr * ldo + gn, v);
+      finish_act<8>(act, gr, gn, v, cc.bi);
     }
+  }
+  template <int N>
+  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += bi[j];
+    if (a == ACT_SILU) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = silu_exact(v[j]);
+    } else if (a == ACT_GELU) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = gelu_erf(v[j]);
+    }
+    float* p = out + (long)gr * ldo + gn;
+#pragma unroll
+    for (int j = 0; j < N; j += 4) gst16f(p + j, v[j], v[j + 1], v[j + 2], v[j + 3]);
+  }
+  static constexpr int LANE_CHUNK = 4;
+  template <int N>
+  TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) bi[j] = 0.f;
+    if (bias) g_loadn<N>(bias + gn, bi);
   }
 };
 

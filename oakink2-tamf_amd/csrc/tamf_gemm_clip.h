@@ -59,7 +59,7 @@ struct ClipGemmArgs {
   int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after a tile's first K tile, 2 = no MFMAs, 4 = no epilogue
 };
 
-template <int NSUB, int NI, int XSUB>
+template <int NSUB, int NI, int XSUB, int CH>
 struct ClipCfg {
   static constexpr int MT = NSUB * 16;        // tile rows (>= Sp)
   static constexpr int BN = 64 * NI;          // tile columns: 4 waves x NI MFMA column tiles
@@ -69,49 +69,71 @@ struct ClipCfg {
   static constexpr int ROWS = MT + BN;        // rows of one staged K tile: A rows then W rows
   static constexpr int STAGE = ROWS * GEMM_BKB;
   static constexpr int NPIECE = ROWS / 8, A_PIECES = MT / 8;
-  static constexpr int SLAB = 64;             // rows per epilogue slab
-  static constexpr int LDC = BN + 4;
-  static constexpr int C_OFF = STAGE;         // the C slab overlays stage 1: stage 0 stays free for the next tile's first K tile
-  static constexpr int CBYTES = SLAB * LDC * 4;
-  static constexpr int BYTES = (2 * STAGE > C_OFF + CBYTES) ? 2 * STAGE : C_OFF + CBYTES;
+  static constexpr int CHUNK = CH;             // consecutive output columns of a lane per store (clip_wperm)
+  static constexpr int NCHUNK = 4 * NI / CH;  // such chunks per lane and row tile, CH * 4 columns apart
+  static_assert(NI % 2 == 0, "column tiles per wave");
+  static constexpr int BYTES = 2 * STAGE;     // two stages; the epilogue goes from registers to HBM
   static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
+// Column order of a tile.  The MFMAs take W as their ROW operand, so lane (lr, g) of a wave ends up with row lr of a row tile
+// and, per column tile ni, the outputs of the four staged W rows 16 ni + 4 g + {0..3} of the wave's column block: four
+// consecutive columns.  That is what a 4-byte output wants - one 16-byte store per lane and column tile, the four lane groups
+// of a row filling 64 contiguous bytes per instruction (CH = 4: no permutation).  A 16-bit output plane wants EIGHT consecutive
+// columns per lane and store: W row wperm(s) is staged at row s - a permutation of bits 2..4 inside every 32 rows, applied
+// on the SOURCE side of the LDS-DMA - so that column tiles 2c and 2c + 1 together hold columns 32 c + 8 g + {0..7} (CH = 8).
+// Either way a lane stores whole 16-byte pieces of its output row straight from the accumulators, every store instruction
+// writes 64-byte runs, and the fp32 tile never passes through LDS.
+template <int CH>
+TAMF_DEV int clip_wperm(int s) {
+  static_assert(CH == 4 || CH == 8, "columns per lane and store");
+  if constexpr (CH == 8) {
+    return (s & ~28) | ((s >> 2) & 4) | ((s << 1) & 24);  // staged bits [3:2] (g) -> [4:3], [4] (ni & 1) -> [2]
+  } else {
+    return s;
+  }
+}
 // Source addressing of the LDS-DMA pieces of one tile.  Piece q covers staged rows [8q, 8q + 8) (lane: row 8q + lane / 8,
-// 16-byte chunk lane % 8, XOR-swizzled by the row on the SOURCE side); rows < MT are the clip's A rows (clamped to the
-// clip), the others the W rows of the column tile.  A wave takes pieces q0, q0 + QS, q0 + 2 QS, ...: their rows are
-// 8 QS apart, a multiple of 16, so the swizzle term is the same for all of them and each piece's offset is one add.
+// 16-byte chunk lane % 8, XOR-swizzled by the STAGED row on the source side); rows < MT are the clip's A rows (clamped to the
+// clip), the others the W rows of the column tile in clip_wperm order.  Loader wave nq takes pieces nq, nq + 4, nq + 8, ...:
+// their staged rows are 32 apart, so the swizzle term is the same for all of them; the staged W row of piece nq + 4 i is
+// el + lane / 8 + 32 (i + hq) with el < 32, and clip_wperm, a bit permutation, splits into a per-lane term and a per-piece
+// (scalar) term.
 struct ClipSrc {
-  unsigned a0, a_last, w0;  // byte offsets from A / W of the lane's row in piece q0 (A: unclamped; clamped last row; W)
+  unsigned a0, a_last, w0;  // byte offsets from A / W of the lane's row in piece nq (A: unclamped; clamped last row; W: permuted)
+  int hq;                   // 32-row block of W piece nq + 4 i: i + hq
 };
 template <class Op, class C>
-TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int q0, int prow, int pch) {
-  const int r0 = q0 * 8 + prow;
+TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int nq, int prow, int pch) {
+  const int r0 = nq * 8 + prow;
   const unsigned swz = (unsigned)((pch ^ swz_chunk<GEMM_BKB>(r0)) << 4);
   const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
+  const int e = nq * 8 - C::MT;  // staged W row of (virtual) piece nq, lane row 0: negative
   ClipSrc s;
   s.a0 = (unsigned)(b * ga.Sp + r0) * ldaB + swz;
   s.a_last = (unsigned)(b * ga.Sp + ga.Sp - 1) * ldaB + swz;
-  s.w0 = (unsigned)(n0 + r0 - C::MT) * ldwB + swz;  // wraps for rows < MT, where it is not used
+  s.w0 = (unsigned)(n0 + clip_wperm<C::CHUNK>((e & 31) + prow)) * ldwB + swz;
+  s.hq = e >> 5;
   return s;
 }
-// issue pieces q0 + QS i (i = 0 .. ) of K tile kt into the stage at `stage_base`
-template <class Op, class C, int QS>
-TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int q0, int prow, int kt, char* stage_base) {
+// issue pieces nq + 4 i (i = 0 .. ) of K tile kt into the stage at `stage_base`
+template <class Op, class C>
+TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, int prow, int kt, char* stage_base) {
+  constexpr int QS = 4;
   constexpr int NI_ = (C::NPIECE + QS - 1) / QS;
   const char* Ab = (const char*)ga.A;
   const char* Wb = (const char*)ga.W;
   const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
 #pragma unroll
   for (int i = 0; i < NI_; ++i) {
-    const int q = q0 + QS * i;
+    const int q = nq + QS * i;
     if ((i + 1) * QS <= C::NPIECE || q < C::NPIECE) {
       const char* src;
       if (q < C::A_PIECES) {
         const unsigned o = (q * 8 + prow < ga.Sp) ? s.a0 + (unsigned)(QS * 8 * i) * ldaB : s.a_last;
         src = Ab + o;
       } else {
-        src = Wb + (s.w0 + (unsigned)(QS * 8 * i) * ldwB);
+        src = Wb + (s.w0 + (unsigned)clip_wperm<C::CHUNK>(32 * (i + s.hq)) * ldwB);
       }
       glds16<0>(src + (long)kt * GEMM_BKB, stage_base + q * 1024);
     }
@@ -141,7 +163,7 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
-  if (load_next) clip_issue<Op, C, 4>(ga, src4, nq, prow, kt_next, nxt);
+  if (load_next) clip_issue<Op, C>(ga, src4, nq, prow, kt_next, nxt);
   TAMF_CLIP_TS(1)
 #pragma unroll
   for (int mi = 0; mi < C::MSUBX; ++mi) {
@@ -187,16 +209,60 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
   return (int)blockIdx.x < cnt ? base + xcd_remap(blockIdx.x, cnt) : -1;
 }
 
+// Register epilogue of one wave: row tile mi of the wave -> row row0 + 16 mi of the clip; chunk c of the lane = columns
+// gn + 4 CH c .. + CH (column tile c for CH = 4, column tiles 2c and 2c + 1 for CH = 8)
+template <class C, int NI, int MS, int ACT, class Epi>
+TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
+                                  const float (&bi)[C::NCHUNK][C::CHUNK]) {
+  constexpr int CH = C::CHUNK;
+#pragma unroll
+  for (int mi = 0; mi < MS; ++mi) {
+    const int r = row0 + mi * 16;
+    if (r < Sp) {
+#pragma unroll
+      for (int c = 0; c < C::NCHUNK; ++c) {
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = acc[mi][c * (CH / 4) + j / 4][j % 4];
+        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c]);
+      }
+    }
+  }
+}
+template <class C, int NI, int MS, class Epi>
+TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
+                              const float (&bi)[C::NCHUNK][C::CHUNK]) {
+  if (epi.act == ACT_GELU) {
+    clip_store_rows_act<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi);
+  } else if (epi.act == ACT_SILU) {
+    clip_store_rows_act<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi);
+  } else {
+    clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi);
+  }
+}
+
+// a (free) register use that makes the compiler wait for the column constants HERE, once, and not at their first use inside
+// the row loop - where the wait would be repeated per row tile and then also cover the previous row tile's stores
+template <int NC, int CH>
+TAMF_DEV void clip_settle(const float (&bi)[NC][CH]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) asm volatile("" ::"v"(bi[c][j]));
+}
+
+// barrier of the Y waves: they issue no loads, and their epilogue stores may drain behind it (no vmcnt wait)
+TAMF_DEV void clip_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class Op, int NSUB, int NI, int XSUB, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
-  typedef ClipCfg<NSUB, NI, XSUB> C;
+  typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   constexpr int BKB = GEMM_BKB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;  // (& 7: lets the compiler fold the piece bounds)
   const int lr = lane & 15, g = lane >> 4;
   const int mh = wave >> 2, nq = wave & 3;
-  const int msub = mh ? C::MSUBY : C::MSUBX;
   static_assert(C::MSUBX >= 2 && C::MSUBY >= 1, "row tiles per wave half");
   const int wm0 = mh * C::MSUBX * 16, wn0 = nq * (NI * 16);
   const int KT = (ga.K * Op::EB) / BKB;
@@ -208,27 +274,28 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int c0 = ((g ^ sw) << 4), c1 = (((4 + g) ^ sw) << 4);
   const int a_frag = (wm0 + lr) * BKB;
   const int w_frag = (C::MT + wn0 + lr) * BKB;
+  const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
 
   int round = 0;
   int t = clip_tile_of(ga.n_tiles, round);
   if (t < 0) return;
-  // a tile's first K tile is requested by all eight waves (pieces wave, wave + 8, ...)
-  clip_issue<Op, C, 8>(ga, clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, wave, prow, pch), wave, prow, 0, smem);
-  while (true) {
-    const int b = t / ntn, n0 = (t % ntn) * C::BN;
-    const int m0 = b * ga.Sp;
-    const ClipSrc src4 = clip_src<Op, C>(ga, b, n0, nq, prow, pch);  // loader role: pieces nq, nq + 4, ...
-    f32x4 acc[C::MSUB0][NI];
-#pragma unroll
-    for (int mi = 0; mi < C::MSUB0; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();  // K tile 0 has landed (vmcnt(0) + barrier); the previous tile's C slab has been consumed
 
-    // KT + 1 barrier intervals: X multiplies K tile `it` in interval `it`, Y in interval `it + 1`.  Two separate loops
-    // (not one loop with a branch inside): Y's fragment registers are loop-carried and would otherwise be live - and spilled -
-    // across X's code.  Both loops execute the same KT + 1 barriers.
-    if (mh == 0) {
+  // KT + 1 barrier intervals per tile: X multiplies K tile `it` in interval `it`, Y in interval `it + 1`; a tile's interval 0
+  // begins when its first K tile has landed.  Two separate loops (not one loop with a branch inside): Y's fragment registers
+  // are loop-carried and would otherwise be live - and spilled - across X's code.  Both execute the same barriers.
+  if (mh == 0) {
+    // X: the loaders.  After the barrier that ends interval KT - 1 nobody reads LDS any more (Y holds the last fragments in
+    // registers), so X requests the NEXT tile's first K tile at once and stores its rows while Y multiplies the last K tile.
+    clip_issue<Op, C>(ga, clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, nq, prow, pch), nq, prow, 0, smem);
+    while (true) {
+      const int b = t / ntn, n0 = (t % ntn) * C::BN;
+      const ClipSrc src4 = clip_src<Op, C>(ga, b, n0, nq, prow, pch);
+      f32x4 acc[C::MSUB0][NI];
+#pragma unroll
+      for (int mi = 0; mi < C::MSUBX; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();  // K tile 0 has landed (vmcnt(0): also this wave's stores of the previous tile) + barrier
       for (int it = 0; it < KT; ++it) {
         const int cur = it & 1;
 #ifdef TAMF_TIMELINE
@@ -246,16 +313,33 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         __syncthreads();  // the next K tile has landed (vmcnt(0)); barrier
 #endif
       }
-      __syncthreads();
-    } else {
-      // Y's MFMAs go first on the SIMD (static priority, no per-interval flips): they are ready at the top of the interval,
-      // while X spends its head on the DMA pieces anyway; served from the leftovers of the older X wave (equal priority:
-      // the older wave wins arbitration) Y finished LAST - 2 620 of 3 300 cycles - and its fragment reads and the barrier
-      // followed with the matrix pipe idle.  With priority Y is done after ~1 200 cycles and reads while X multiplies.
-      __builtin_amdgcn_s_setprio(2);
+      float bi[C::NCHUNK][C::CHUNK];
+#pragma unroll
+      for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+      const int tn = clip_tile_of(ga.n_tiles, ++round);
+      if (tn >= 0) clip_issue<Op, C>(ga, clip_src<Op, C>(ga, tn / ntn, (tn % ntn) * C::BN, nq, prow, pch), nq, prow, 0, smem);
+      clip_settle(bi);
+      if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+      if (tn < 0) break;
+      t = tn;
+    }
+  } else {
+    // Y's MFMAs go first on the SIMD (static priority, no per-interval flips): they are ready at the top of the interval,
+    // while X spends its head on the DMA pieces anyway; served from the leftovers of the older X wave (equal priority:
+    // the older wave wins arbitration) Y finished LAST - 2 620 of 3 300 cycles - and its fragment reads and the barrier
+    // followed with the matrix pipe idle.  With priority Y is done after ~1 200 cycles and reads while X multiplies.
+    __builtin_amdgcn_s_setprio(2);
+    while (true) {
+      const int b = t / ntn, n0 = (t % ntn) * C::BN;
+      f32x4 acc[C::MSUB0][NI];
+#pragma unroll
+      for (int mi = 0; mi < C::MSUBY; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      clip_barrier_lds();  // K tile 0 has landed (X waited for it)
       int4 ywf[NI][2], yaf[C::MSUBY][2];
       clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
-      __syncthreads();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
+      clip_barrier_lds();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
       for (int it = 1; it < KT; ++it) {
 #ifdef TAMF_TIMELINE
         const bool dbg_on = wave == 4 && round == 0 && it >= 4 && it < 12 && blockIdx.x < 512;
@@ -272,46 +356,19 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         TAMF_CLIP_TS(2)
-        __syncthreads();
+        clip_barrier_lds();
         TAMF_CLIP_TS(3)
       }
+      float bi[C::NCHUNK][C::CHUNK];
+#pragma unroll
+      for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
       if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
+      clip_settle(bi);
+      if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+      const int tn = clip_tile_of(ga.n_tiles, ++round);
+      if (tn < 0) break;
+      t = tn;
     }
-
-    // Epilogue in slabs of 64 rows: a wave parks the row tiles it holds that fall into the slab, then all 8 waves walk it.
-    // The slab barriers wait for the LDS only (s_waitcnt lgkmcnt(0) + s_barrier, not __syncthreads(), whose vmcnt(0) would
-    // wait for the acknowledgement of every global store of the slab before the next one may start), and the per-thread
-    // column constants (bias) are fetched once, ahead of the first store: vmcnt retires in order, so a load issued behind
-    // stores would wait for them just the same.
-    float* Ct = (float*)(smem + C::C_OFF);
-    constexpr int NSLAB = (C::MT + C::SLAB - 1) / C::SLAB;
-    const typename Epi::Cols cc = epi.template cols<C::BN, 512>(n0, tid);
-    cc.settle();
-#pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl) {
-#pragma unroll
-      for (int mi = 0; mi < C::MSUB0; ++mi) {
-        const int s = mh * C::MSUBX + mi;  // row tile of the clip
-        if (mi < msub && (s >> 2) == sl) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const f32x4 v = acc[mi][ni];
-            *(float4*)(Ct + ((s & 3) * 16 + lr) * C::LDC + wn0 + ni * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (!(ga.abl & 4)) epi.template run_c<C::SLAB, C::BN, 512>(Ct, C::LDC, m0 + sl * C::SLAB, n0, m0 + ga.Sp, tid, cc);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // the next tile's first K tile (stage 0) is requested behind the epilogue: in front of it, hipcc would put a vmcnt(0) before
-    // every LDS access of the epilogue (it does so for any LDS access that follows an LDS-DMA in program order)
-    const int tn = clip_tile_of(ga.n_tiles, ++round);
-    const bool more = tn >= 0;
-    if (more) clip_issue<Op, C, 8>(ga, clip_src<Op, C>(ga, tn / ntn, (tn % ntn) * C::BN, wave, prow, pch), wave, prow, 0, smem);
-    if (!more) break;
-    t = tn;
+    __builtin_amdgcn_s_setprio(0);
   }
 }

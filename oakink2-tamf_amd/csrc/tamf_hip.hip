@@ -288,7 +288,7 @@ template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? 6 : 4
 template <class Op, int NI, class Epi>
 struct ClipLaunch {
   static constexpr int XSUB = ClipXsub<NI>::value;
-  typedef ClipCfg<13, NI, XSUB> C;
+  typedef ClipCfg<13, NI, XSUB, Epi::LANE_CHUNK> C;
   static hipError_t prepare() {
     static bool done[64] = {};
     int dev = 0;
