@@ -38,8 +38,11 @@
 
 #ifdef TAMF_TIMELINE  // debug build (tools/clip_timeline.py): shader-clock stamps of waves 0 (X) and 4 (Y) of every workgroup
 __device__ unsigned long long g_clip_ts[512 * 2 * 8 * 4];  // [workgroup][X|Y][interval 4..11][4 stamps]
+#ifndef TAMF_TIMELINE_NI  // (-DTAMF_TIMELINE_NI=2: only the 128-column launches stamp - for runs of the whole step)
+#define TAMF_TIMELINE_NI NI
+#endif
 #define TAMF_CLIP_TS(slot)                                                                     \
-  if (dbg_on) {                                                                                 \
+  if (dbg_on && NI == TAMF_TIMELINE_NI) {                                                                                 \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
     if (lane_dbg == 0) g_clip_ts[((blockIdx.x * 2 + mh_dbg) * 8 + (it_dbg - 4)) * 4 + (slot)] = t_; \
   }
