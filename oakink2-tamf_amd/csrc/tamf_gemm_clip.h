@@ -75,8 +75,13 @@ struct ClipCfg {
   static constexpr int CHUNK = CH;             // consecutive output columns of a lane per store (clip_wperm)
   static constexpr int NCHUNK = 4 * NI / CH;  // such chunks per lane and row tile, CH * 4 columns apart
   static_assert(NI % 2 == 0, "column tiles per wave");
-  static constexpr int BYTES = 2 * STAGE;     // two stages; the epilogue goes from registers to HBM
+  // stages of the K-tile stream (the epilogue goes from registers to HBM and needs no LDS): three where they fit - the
+  // 128-column tiles - i.e. the LDS-DMA of a K tile is issued TWO intervals before its first read
+  static constexpr int NSTAGE = (3 * STAGE <= 160 * 1024) ? 3 : 2;
+  static constexpr int BYTES = NSTAGE * STAGE;
   static_assert(BYTES <= 160 * 1024, "LDS budget");
+  // LDS-DMA pieces per K tile of loader wave nq: PIECES_HI for nq < PIECES_REM, else PIECES_HI - 1
+  static constexpr int PIECES_HI = (NPIECE + 3) / 4, PIECES_REM = NPIECE % 4 == 0 ? 4 : NPIECE % 4;
 };
 
 // Column order of a tile.  The MFMAs take W as their ROW operand, so lane (lr, g) of a wave ends up with row lr of a row tile
@@ -256,11 +261,42 @@ TAMF_DEV void clip_settle(const float (&bi)[NC][CH]) {
 
 // barrier of the Y waves: they issue no loads, and their epilogue stores may drain behind it (no vmcnt wait)
 TAMF_DEV void clip_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8]); as a builtin, so that the
+// compiler's own wait-count bookkeeping sees it
+template <int N>
+TAMF_DEV void clip_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// The K tiles this workgroup still has to request, across its tiles: round ri (tile clip_tile_of(ri)), K tile kti
+template <class Op, class C>
+struct ClipStream {
+  ClipSrc s;
+  int ri, kti;
+  bool live;
+  TAMF_DEV void open(const ClipGemmArgs<Op>& ga, int ntn, int nq, int prow, int pch) {
+    ri = 0; kti = 0;
+    load_src(ga, ntn, nq, prow, pch);
+  }
+  TAMF_DEV void load_src(const ClipGemmArgs<Op>& ga, int ntn, int nq, int prow, int pch) {
+    const int t = clip_tile_of(ga.n_tiles, ri);
+    live = t >= 0;
+    if (live) s = clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, nq, prow, pch);
+  }
+  TAMF_DEV void advance(const ClipGemmArgs<Op>& ga, int KT, int ntn, int nq, int prow, int pch) {
+    if (++kti == KT) {
+      kti = 0;
+      ++ri;
+      load_src(ga, ntn, nq, prow, pch);
+    }
+  }
+};
 
 template <class Op, int NSUB, int NI, int XSUB, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
-  constexpr int BKB = GEMM_BKB;
+  constexpr int BKB = GEMM_BKB, NS = C::NSTAGE, LA = NS - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;  // (& 7: lets the compiler fold the piece bounds)
@@ -279,52 +315,78 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int w_frag = (C::MT + wn0 + lr) * BKB;
   const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
 
-  int round = 0;
-  int t = clip_tile_of(ga.n_tiles, round);
-  if (t < 0) return;
+  // The workgroup is persistent over its tiles (rounds of the grid) and treats their K tiles as ONE stream: interval j
+  // belongs to K tile j % KT of round j / KT and lives in stage j % NS.  X multiplies K tile j in interval j and requests K tile
+  // j + LA (possibly the next tile's) into the stage that K tile j - 1 has just left; Y multiplies K tile j - 1 from registers
+  // and reads K tile j.  A tile's rows are stored by X at the head of the next tile's first interval - while Y multiplies
+  // the last K tile - and by Y behind those MFMAs, while X is back in the K loop: no interval without MFMAs, no drain.
+  const int G = gridDim.x;
+  const int my_tiles = ga.n_tiles / G + ((int)blockIdx.x < ga.n_tiles % G ? 1 : 0);
+  if (my_tiles == 0) return;
+  const int J = my_tiles * KT;
 
-  // KT + 1 barrier intervals per tile: X multiplies K tile `it` in interval `it`, Y in interval `it + 1`; a tile's interval 0
-  // begins when its first K tile has landed.  Two separate loops (not one loop with a branch inside): Y's fragment registers
-  // are loop-carried and would otherwise be live - and spilled - across X's code.  Both execute the same barriers.
+  // Two separate loops (not one loop with a branch inside): Y's fragment registers are loop-carried and would otherwise be
+  // live - and spilled - across X's code.  Both execute the same J + 1 barriers.
   if (mh == 0) {
-    // X: the loaders.  After the barrier that ends interval KT - 1 nobody reads LDS any more (Y holds the last fragments in
-    // registers), so X requests the NEXT tile's first K tile at once and stores its rows while Y multiplies the last K tile.
-    clip_issue<Op, C>(ga, clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, nq, prow, pch), nq, prow, 0, smem);
-    while (true) {
-      const int b = t / ntn, n0 = (t % ntn) * C::BN;
-      const ClipSrc src4 = clip_src<Op, C>(ga, b, n0, nq, prow, pch);
-      f32x4 acc[C::MSUB0][NI];
+    ClipStream<Op, C> is;
+    is.open(ga, ntn, nq, prow, pch);
 #pragma unroll
-      for (int mi = 0; mi < C::MSUBX; ++mi)
+    for (int p = 0; p < LA; ++p) {  // (J >= KT >= 2 >= LA)
+      clip_issue<Op, C>(ga, is.s, nq, prow, is.kti, smem + p * C::STAGE);
+      is.advance(ga, KT, ntn, nq, prow, pch);
+    }
+    f32x4 acc[C::MSUB0][NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      __syncthreads();  // K tile 0 has landed (vmcnt(0): also this wave's stores of the previous tile) + barrier
-      for (int it = 0; it < KT; ++it) {
-        const int cur = it & 1;
+    for (int mi = 0; mi < C::MSUBX; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K tile 0 has landed: everything but the LA - 1 requests behind it
+    if constexpr (LA == 2) {
+      if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
+    } else {
+      clip_wait_vm<0>();
+    }
+    clip_barrier_lds();
+    int round = 0, kt = 0, sc = 0, sn = LA % NS;
+    int t = clip_tile_of(ga.n_tiles, 0);
+    for (int j = 0; j < J; ++j) {
+      const bool ld = is.live && !(ga.abl & 1);
 #ifdef TAMF_TIMELINE
-        const bool dbg_on = wave == 0 && round == 0 && it >= 4 && it < 12 && blockIdx.x < 512;
-        const int it_dbg = it, lane_dbg = lane, mh_dbg = 0;
-        TAMF_CLIP_TS(0)
-        clip_ktile_x<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, (it + 1 < KT) && !(ga.abl & 1), !(ga.abl & 2), ga, src4,
-                                nq, prow, it + 1, a_frag, w_frag, c0, c1, acc, dbg_on, it_dbg, lane_dbg);
-        TAMF_CLIP_TS(2)
-        __syncthreads();
-        TAMF_CLIP_TS(3)
+      const bool dbg_on = wave == 0 && j >= 4 && j < 12 && blockIdx.x < 512;
+      const int it_dbg = j, lane_dbg = lane, mh_dbg = 0;
+      TAMF_CLIP_TS(0)
+      clip_ktile_x<Op, C, NI>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+                              c0, c1, acc, dbg_on, it_dbg, lane_dbg);
+      TAMF_CLIP_TS(2)
 #else
-        clip_ktile_x<Op, C, NI>(smem + cur * C::STAGE, smem + (cur ^ 1) * C::STAGE, (it + 1 < KT) && !(ga.abl & 1), !(ga.abl & 2), ga, src4,
-                                nq, prow, it + 1, a_frag, w_frag, c0, c1, acc);
-        __syncthreads();  // the next K tile has landed (vmcnt(0)); barrier
+      clip_ktile_x<Op, C, NI>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+                              c0, c1, acc);
 #endif
+      if (is.live) is.advance(ga, KT, ntn, nq, prow, pch);
+      // K tile j + 1 has landed: everything but the requests issued behind it (vmcnt retires in order)
+      if (LA == 2 && ld) {
+        if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
+      } else {
+        clip_wait_vm<0>();
       }
-      float bi[C::NCHUNK][C::CHUNK];
+      clip_barrier_lds();
+      TAMF_CLIP_TS(3)
+      sc = sc + 1 == NS ? 0 : sc + 1;
+      sn = sn + 1 == NS ? 0 : sn + 1;
+      if (++kt == KT) {  // the tile is complete: its rows go out while Y multiplies its last K tile
+        const int b = t / ntn, n0 = (t % ntn) * C::BN;
+        float bi[C::NCHUNK][C::CHUNK];
 #pragma unroll
-      for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
-      const int tn = clip_tile_of(ga.n_tiles, ++round);
-      if (tn >= 0) clip_issue<Op, C>(ga, clip_src<Op, C>(ga, tn / ntn, (tn % ntn) * C::BN, nq, prow, pch), nq, prow, 0, smem);
-      clip_settle(bi);
-      if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
-      if (tn < 0) break;
-      t = tn;
+        for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+        clip_settle(bi);
+        if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+#pragma unroll
+        for (int mi = 0; mi < C::MSUBX; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kt = 0;
+        t = clip_tile_of(ga.n_tiles, ++round);
+      }
     }
   } else {
     // Y's MFMAs go first on the SIMD (static priority, no per-interval flips): they are ready at the top of the interval,
@@ -332,45 +394,51 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     // the older wave wins arbitration) Y finished LAST - 2 620 of 3 300 cycles - and its fragment reads and the barrier
     // followed with the matrix pipe idle.  With priority Y is done after ~1 200 cycles and reads while X multiplies.
     __builtin_amdgcn_s_setprio(2);
-    while (true) {
-      const int b = t / ntn, n0 = (t % ntn) * C::BN;
-      f32x4 acc[C::MSUB0][NI];
+    f32x4 acc[C::MSUB0][NI];
 #pragma unroll
-      for (int mi = 0; mi < C::MSUBY; ++mi)
+    for (int mi = 0; mi < C::MSUBY; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      clip_barrier_lds();  // K tile 0 has landed (X waited for it)
-      int4 ywf[NI][2], yaf[C::MSUBY][2];
-      clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
-      clip_barrier_lds();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
-      for (int it = 1; it < KT; ++it) {
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    clip_barrier_lds();  // K tile 0 has landed (X waited for it)
+    int4 ywf[NI][2], yaf[C::MSUBY][2];
+    clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
+    clip_barrier_lds();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
+    int round = 0, kt = 0, sc = 1 % NS;
+    int t = clip_tile_of(ga.n_tiles, 0);
+    for (int j = 1; j <= J; ++j) {
 #ifdef TAMF_TIMELINE
-        const bool dbg_on = wave == 4 && round == 0 && it >= 4 && it < 12 && blockIdx.x < 512;
-        const int it_dbg = it, lane_dbg = lane, mh_dbg = 1;
+      const bool dbg_on = wave == 4 && j >= 4 && j < 12 && blockIdx.x < 512;
+      const int it_dbg = j, lane_dbg = lane, mh_dbg = 1;
 #endif
-        TAMF_CLIP_TS(0)
-        if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
+      TAMF_CLIP_TS(0)
+      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);  // K tile j - 1
 #ifdef TAMF_TIMELINE
-        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
 #endif
-        TAMF_CLIP_TS(1)
-        clip_read_y<C, NI>(smem + (it & 1) * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
-#ifdef TAMF_TIMELINE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        TAMF_CLIP_TS(2)
-        clip_barrier_lds();
-        TAMF_CLIP_TS(3)
+      TAMF_CLIP_TS(1)
+      if (++kt == KT) {
+        const int b = t / ntn, n0 = (t % ntn) * C::BN;
+        float bi[C::NCHUNK][C::CHUNK];
+#pragma unroll
+        for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+        clip_settle(bi);
+        if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+#pragma unroll
+        for (int mi = 0; mi < C::MSUBY; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kt = 0;
+        t = clip_tile_of(ga.n_tiles, ++round);
       }
-      float bi[C::NCHUNK][C::CHUNK];
-#pragma unroll
-      for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
-      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);
-      clip_settle(bi);
-      if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
-      const int tn = clip_tile_of(ga.n_tiles, ++round);
-      if (tn < 0) break;
-      t = tn;
+      if (j == J) break;
+      clip_read_y<C, NI>(smem + sc * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
+#ifdef TAMF_TIMELINE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      TAMF_CLIP_TS(2)
+      clip_barrier_lds();
+      TAMF_CLIP_TS(3)
+      sc = sc + 1 == NS ? 0 : sc + 1;
     }
     __builtin_amdgcn_s_setprio(0);
   }
