@@ -149,6 +149,9 @@ struct OpF32 {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(a[f].w), as_f(b[f].w), acc, 0, 0, 0);
     }
   }
+  // mma_t(acc, x, w): the TRANSPOSE of mma(acc, w, x) - x is the MFMA's row operand - with the same products in the same
+  // order, i.e. the same bits per output element (the V projection stored transposed, tamf_gemm_clip.h)
+  static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) { mma(acc, x, w); }
   // byte offset of logical element idx (row * ld + col; ld % 32 == 0) from the matrix base
   static TAMF_DEV long byte_off(long idx) { return idx * 4; }
   template <int N>
@@ -191,6 +194,7 @@ struct OpBF16 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0, 0);
   }
+  static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) { mma(acc, x, w); }
   static TAMF_DEV long byte_off(long idx) { return idx * 2; }
   template <int N>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
@@ -218,6 +222,11 @@ struct OpBF16X3 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) {  // w_lo.x_hi, w_hi.x_lo, w_hi.x_hi as in mma(acc, w, x)
+    acc = mfma1(x[0], w[1], acc);
+    acc = mfma1(x[1], w[0], acc);
+    acc = mfma1(x[0], w[0], acc);
   }
   // element idx lives in 128-byte group idx / 32: hi at 2 * (idx % 32), lo 64 bytes further
   static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
@@ -261,6 +270,11 @@ struct OpF16X3 {
     acc = mfma1(a[1], b[0], acc);
     acc = mfma1(a[0], b[1], acc);
     acc = mfma1(a[0], b[0], acc);
+  }
+  static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) {  // w_lo.x_hi, w_hi.x_lo, w_hi.x_hi as in mma(acc, w, x)
+    acc = mfma1(x[0], w[1], acc);
+    acc = mfma1(x[1], w[0], acc);
+    acc = mfma1(x[0], w[0], acc);
   }
   static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
   template <int N>

@@ -157,11 +157,51 @@ struct EpiBiasAct {
   }
   // register form: a lane stores 16 bytes per instruction - 4 columns of a 4-byte output, 8 of a 16-bit plane
   static constexpr int LANE_CHUNK = OutOp::PREC == 0 ? 4 : 8;
+  static constexpr bool TRANSPOSED = false;
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
 #pragma unroll
     for (int j = 0; j < N; ++j) bi[j] = 0.f;
     if (bias) g_loadn<N>(bias + gn, bi);
+  }
+};
+
+// The same projection as two clip-tile launches (tamf_gemm_clip.h): EpiQK = its Q and K columns (register form only), EpiVt =
+// its V columns with the MFMA operands exchanged, so that a lane ends up with runs of consecutive KEYS of one feature - what
+// a V^T row stores.  Same operations per element as EpiQKV::run, i.e. the same bits.
+template <class Op>
+struct EpiQK {
+  const float* bias;  // [2d] (the Q and K parts of in_proj_bias)
+  typename Op::elem_t* qk;
+  int d;
+  float qscale;
+  int act;  // (ACT_NONE; the register epilogue dispatches on it)
+  static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
+  static constexpr bool TRANSPOSED = false;
+  template <int N>
+  TAMF_DEV void finish_act(int, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+    const float sc = (gn < d) ? qscale : 1.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = (v[j] + bi[j]) * sc;
+    Op::template store<N>(qk, (long)gr * (2 * d) + gn, v);
+  }
+  template <int N>
+  TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const { g_loadn<N>(bias + gn, bi); }
+};
+template <class Op>
+struct EpiVt {
+  const float* bias;  // [d] (the V part of in_proj_bias)
+  typename Op::elem_t* vt;
+  int H, hd, Skp;
+  int act;
+  static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
+  static constexpr bool TRANSPOSED = true;
+  // feature eg (column of the V block) of clip b: N stored key positions from pos0 (N = 8: one 16-byte piece per 16-bit plane,
+  // the keys 4g .. 4g+3 of two consecutive 16-key groups, vt_key_pos; N = 4: four consecutive keys, f32)
+  template <int N>
+  TAMF_DEV void store_keys(int b, int eg, int pos0, const float (&v)[N]) const {
+    const int h = eg / hd, e = eg % hd;
+    Op::template store<N>(vt, ((long)(b * H + h) * hd + e) * Skp + pos0, v);
   }
 };
 
@@ -503,6 +543,7 @@ struct EpiStoreF32 {
     for (int j = 0; j < N; j += 4) gst16f(p + j, v[j], v[j + 1], v[j + 2], v[j + 3]);
   }
   static constexpr int LANE_CHUNK = 4;
+  static constexpr bool TRANSPOSED = false;
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
 #pragma unroll

@@ -59,7 +59,8 @@ struct ClipGemmArgs {
   int n_clips, Sp;  // A has n_clips * Sp rows; a tile covers rows [b*Sp, b*Sp + Sp)
   int N, K;
   int n_tiles;      // n_clips * (N / BN)
-  int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after a tile's first K tile, 2 = no MFMAs, 4 = no epilogue
+  int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after the first K tiles, 2 = no MFMAs, 4 = no epilogue,
+                    // 8 = no activation, 16 = every row tile is stored into the rows of the first one (no new lines to write back)
 };
 
 template <int NSUB, int NI, int XSUB, int CH>
@@ -78,7 +79,9 @@ struct ClipCfg {
   // stages of the K-tile stream (the epilogue goes from registers to HBM and needs no LDS): three where they fit - the
   // 128-column tiles - i.e. the LDS-DMA of a K tile is issued TWO intervals before its first read
   static constexpr int NSTAGE = (3 * STAGE <= 160 * 1024) ? 3 : 2;
-  static constexpr int BYTES = NSTAGE * STAGE;
+  // + a lane-private scratch row tile per wave (16 bytes x NI per lane) for the rolled form of an epilogue with an activation
+  static constexpr int SCRATCH_OFF = NSTAGE * STAGE, SCRATCH_WAVE = NI * 1024;
+  static constexpr int BYTES = SCRATCH_OFF + 8 * SCRATCH_WAVE;
   static_assert(BYTES <= 160 * 1024, "LDS budget");
   // LDS-DMA pieces per K tile of loader wave nq: PIECES_HI for nq < PIECES_REM, else PIECES_HI - 1
   static constexpr int PIECES_HI = (NPIECE + 3) / 4, PIECES_REM = NPIECE % 4 == 0 ? 4 : NPIECE % 4;
@@ -152,7 +155,7 @@ TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, i
 // `nxt`, then the MFMAs run with the A fragments streamed two row tiles ahead.  `cur` and `nxt` are the two LDS stages and
 // never overlap; the __restrict__ qualifiers of this (inlined) helper are what keeps hipcc from placing an s_waitcnt vmcnt(0)
 // in front of the LDS reads that follow the LDS-DMA in program order (as in tamf_attn.h).
-template <class Op, class C, int NI>
+template <class Op, class C, int NI, bool TR>
 TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt, bool load_next, bool compute,
                            const ClipGemmArgs<Op>& ga, const ClipSrc& src4, int nq, int prow, int kt_next, int a_frag, int w_frag,
                            int c0, int c1, f32x4 (&acc)[C::MSUB0][NI], bool dbg_on = false, int it_dbg = 0, int lane_dbg = 0) {
@@ -181,7 +184,10 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
     }
     if (compute) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g + reg), cols = m (lr)
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (TR) Op::mma_t(acc[mi][ni], af[mi], wf[ni]);  // D rows = m (4g + reg), cols = n (lr)
+        else Op::mma(acc[mi][ni], wf[ni], af[mi]);                 // D rows = n (4g + reg), cols = m (lr)
+      }
     }
   }
 }
@@ -200,12 +206,15 @@ TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
 }
-template <class Op, class C, int NI>
+template <class Op, class C, int NI, bool TR>
 TAMF_DEV void clip_mma_y(const int4 (&wf)[NI][2], const int4 (&af)[C::MSUBY][2], f32x4 (&acc)[C::MSUB0][NI]) {
 #pragma unroll
   for (int mi = 0; mi < C::MSUBY; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) Op::mma(acc[mi][ni], wf[ni], af[mi]);
+    for (int ni = 0; ni < NI; ++ni) {
+      if constexpr (TR) Op::mma_t(acc[mi][ni], af[mi], wf[ni]);
+      else Op::mma(acc[mi][ni], wf[ni], af[mi]);
+    }
 }
 
 // tile of this workgroup in round `r` of the persistent grid (-1: none): inside a round the XCDs own contiguous chunks of
@@ -219,13 +228,13 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
 
 // Register epilogue of one wave: row tile mi of the wave -> row row0 + 16 mi of the clip; chunk c of the lane = columns
 // gn + 4 CH c .. + CH (column tile c for CH = 4, column tiles 2c and 2c + 1 for CH = 8)
-template <class C, int NI, int MS, int ACT, class Epi>
+template <class C, int NI, int MS, int ACT, bool ONE_ROW_TILE = false, class Epi>
 TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
                                   const float (&bi)[C::NCHUNK][C::CHUNK]) {
   constexpr int CH = C::CHUNK;
 #pragma unroll
   for (int mi = 0; mi < MS; ++mi) {
-    const int r = row0 + mi * 16;
+    const int r = ONE_ROW_TILE ? row0 : row0 + mi * 16;
     if (r < Sp) {
 #pragma unroll
       for (int c = 0; c < C::NCHUNK; ++c) {
@@ -237,15 +246,107 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
     }
   }
 }
+// The same with the row tiles in a LOOP, for the epilogues that carry an activation: unrolled, the GELU of 6 / 7 row tiles is
+// 11 - 13 KB of straight-line code per wave role that every launch fetches once, cold (in the step the kernels alternate; measured
+// in situ: FFN1 82.6 us unrolled against 79.5 us with the looped LDS-walking epilogue it replaced).  A loop cannot index the
+// accumulator registers, so the row tile of the iteration takes a round trip through a lane-private LDS slot (4 NI floats per
+// lane: NI ds_write_b128 + NI ds_read_b128, conflict-free, no barrier), selected by a scalar branch.
+template <class C, int NI, int MS, int ACT, class Epi>
+TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
+                                     const float (&bi)[C::NCHUNK][C::CHUNK], char* slot /* wave scratch + 16 * lane */) {
+  constexpr int CH = C::CHUNK;
+#pragma clang loop unroll(disable)
+  for (int mi = 0; mi < MS; ++mi) {
+#pragma unroll
+    for (int k = 0; k < MS; ++k)
+      if (mi == k) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4*)(slot + ni * 1024) = acc[k][ni];
+      }
+    f32x4 a[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) a[ni] = *(const volatile f32x4*)(slot + ni * 1024);
+    const int r = row0 + mi * 16;
+    if (r < Sp) {
+#pragma unroll
+      for (int c = 0; c < C::NCHUNK; ++c) {
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = a[c * (CH / 4) + j / 4][j % 4];
+        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c]);
+      }
+    }
+  }
+}
 template <class C, int NI, int MS, class Epi>
 TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                              const float (&bi)[C::NCHUNK][C::CHUNK]) {
+                              const float (&bi)[C::NCHUNK][C::CHUNK], int abl, char* slot) {
+  if (abl & 24) {  // (benchmark ablations)
+    if (abl & 16) { Sp = 0x7fffffff; m0 = 0; row0 &= 15; }
+    if (abl & 16) {
+      f32x4 a1[C::MSUB0][NI];
+#pragma unroll
+      for (int mi = 0; mi < MS; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) a1[mi][ni] = acc[mi][ni];
+      // rows of the first row tile only: the same lines again and again
+      if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_act<C, NI, MS, ACT_GELU, true>(epi, a1, row0, Sp, m0, gn, bi);
+      else clip_store_rows_act<C, NI, MS, ACT_NONE, true>(epi, a1, row0, Sp, m0, gn, bi);
+    } else {
+      clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi);
+    }
+    return;
+  }
   if (epi.act == ACT_GELU) {
-    clip_store_rows_act<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi);
+    clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot);
   } else if (epi.act == ACT_SILU) {
-    clip_store_rows_act<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi);
+    clip_store_rows_rolled<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi, slot);
   } else {
     clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi);
+  }
+}
+
+// Register epilogue of the transposed form (EpiVt): lane (lr, g) holds, per row tile and column tile ni, feature
+// n0 + wn0 + 16 ni + lr of the four tokens 16 s + 4 g + {0..3} of row tile s.  In the 16-bit modes the keys 4g .. 4g+3 of the
+// two 16-key groups of a 32-key block are adjacent in a V^T row (vt_key_pos), so the row tiles 2u and 2u + 1 of a wave give one
+// 16-byte piece per plane; f32 keeps the natural key order, one piece per row tile.  Tokens >= Sp are written as zeros
+// (they are padding keys: the row tile past the clip, and the clamped rows of its last one).  FIRST = the wave's first row tile
+// (even: XSUB is), MS its row tiles.
+template <class Op, class C, int NI, int FIRST, int MS, class Epi>
+TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int g, int Sp, int b, int eg0 /* feature of ni = 0 */,
+                            const float (&bb)[NI]) {
+  static_assert(FIRST % 2 == 0, "row-tile pairs must not straddle the X / Y split");
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bb[ni]));  // (one wait, ahead of the stores)
+  if constexpr (Op::PREC == 0) {
+#pragma unroll
+    for (int mi = 0; mi < MS; ++mi) {
+      const int tok = (FIRST + mi) * 16 + 4 * g;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? acc[mi][ni][j] + bb[ni] : 0.f;
+        epi.template store_keys<4>(b, eg0 + 16 * ni, tok, v);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < (MS + 1) / 2; ++u) {
+      const int s0 = FIRST + 2 * u;  // row tiles s0 and s0 + 1: keys 16 s0 + 4g + j and 16 (s0 + 1) + 4g + j
+      const int tok0 = s0 * 16 + 4 * g, tok1 = tok0 + 16;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = tok0 < Sp ? acc[2 * u][ni][j] + bb[ni] : 0.f;
+          if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? acc[2 * u + 1][ni][j] + bb[ni] : 0.f;
+          else v[4 + j] = 0.f;
+        }
+        epi.template store_keys<8>(b, eg0 + 16 * ni, (s0 >> 1) * 32 + 8 * g, v);
+      }
+    }
   }
 }
 
@@ -297,6 +398,7 @@ template <class Op, int NSUB, int NI, int XSUB, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   constexpr int BKB = GEMM_BKB, NS = C::NSTAGE, LA = NS - 1;
+  constexpr bool TR = Epi::TRANSPOSED;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;  // (& 7: lets the compiler fold the piece bounds)
@@ -314,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int a_frag = (wm0 + lr) * BKB;
   const int w_frag = (C::MT + wn0 + lr) * BKB;
   const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
+  char* slot = smem + C::SCRATCH_OFF + wave * C::SCRATCH_WAVE + lane * 16;
 
   // The workgroup is persistent over its tiles (rounds of the grid) and treats their K tiles as ONE stream: interval j
   // belongs to K tile j % KT of round j / KT and lives in stage j % NS.  X multiplies K tile j in interval j and requests K tile
@@ -349,22 +452,25 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     clip_barrier_lds();
     int round = 0, kt = 0, sc = 0, sn = LA % NS;
     int t = clip_tile_of(ga.n_tiles, 0);
+    bool pre = false;  // this interval's requests went out ahead of the previous tile's epilogue
     for (int j = 0; j < J; ++j) {
-      const bool ld = is.live && !(ga.abl & 1);
+      const bool ld = is.live && !(ga.abl & 1) && !pre, batch = ld || pre;
 #ifdef TAMF_TIMELINE
       const bool dbg_on = wave == 0 && j >= 4 && j < 12 && blockIdx.x < 512;
       const int it_dbg = j, lane_dbg = lane, mh_dbg = 0;
       TAMF_CLIP_TS(0)
-      clip_ktile_x<Op, C, NI>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
                               c0, c1, acc, dbg_on, it_dbg, lane_dbg);
       TAMF_CLIP_TS(2)
 #else
-      clip_ktile_x<Op, C, NI>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
                               c0, c1, acc);
 #endif
-      if (is.live) is.advance(ga, KT, ntn, nq, prow, pch);
-      // K tile j + 1 has landed: everything but the requests issued behind it (vmcnt retires in order)
-      if (LA == 2 && ld) {
+      if (is.live && !pre) is.advance(ga, KT, ntn, nq, prow, pch);
+      pre = false;
+      // K tile j + 1 has landed: everything but the requests issued behind it (vmcnt retires in order; in a tile's first interval
+      // the epilogue's loads and stores sit behind this interval's requests, and the wait covers those too - it is a long interval)
+      if (LA == 2 && batch) {
         if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
       } else {
         clip_wait_vm<0>();
@@ -375,11 +481,28 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       sn = sn + 1 == NS ? 0 : sn + 1;
       if (++kt == KT) {  // the tile is complete: its rows go out while Y multiplies its last K tile
         const int b = t / ntn, n0 = (t % ntn) * C::BN;
+        // column constants, then the next interval's requests (the epilogue must not delay them; and vmcnt retires in order: the
+        // constants are waited for with the requests still in flight), then the rows
         float bi[C::NCHUNK][C::CHUNK];
+        float bb[NI];
+        if constexpr (TR) {
 #pragma unroll
-        for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
-        clip_settle(bi);
-        if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+          for (int ni = 0; ni < NI; ++ni) bb[ni] = epi.bias[n0 + wn0 + lr + 16 * ni];
+        } else {
+#pragma unroll
+          for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+        }
+        if (is.live && !(ga.abl & 1)) {
+          clip_issue<Op, C>(ga, is.s, nq, prow, is.kti, smem + sn * C::STAGE);
+          is.advance(ga, KT, ntn, nq, prow, pch);
+          pre = true;
+        }
+        if constexpr (TR) {
+          if (!(ga.abl & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+        } else {
+          clip_settle(bi);
+          if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, ga.abl, slot);
+        }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBX; ++mi)
 #pragma unroll
@@ -411,18 +534,25 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       const int it_dbg = j, lane_dbg = lane, mh_dbg = 1;
 #endif
       TAMF_CLIP_TS(0)
-      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI>(ywf, yaf, acc);  // K tile j - 1
+      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI, TR>(ywf, yaf, acc);  // K tile j - 1
 #ifdef TAMF_TIMELINE
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
 #endif
       TAMF_CLIP_TS(1)
       if (++kt == KT) {
         const int b = t / ntn, n0 = (t % ntn) * C::BN;
-        float bi[C::NCHUNK][C::CHUNK];
+        if constexpr (TR) {
+          float bb[NI];
 #pragma unroll
-        for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
-        clip_settle(bi);
-        if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi);
+          for (int ni = 0; ni < NI; ++ni) bb[ni] = epi.bias[n0 + wn0 + lr + 16 * ni];
+          if (!(ga.abl & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+        } else {
+          float bi[C::NCHUNK][C::CHUNK];
+#pragma unroll
+          for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+          clip_settle(bi);
+          if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, ga.abl, slot);
+        }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBY; ++mi)
 #pragma unroll

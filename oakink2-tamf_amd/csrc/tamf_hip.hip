@@ -202,7 +202,7 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
-// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode
+// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -284,7 +284,13 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 // rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
 // else runs on the 128 x 128 tiles.
 // row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the 13 row tiles
-template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? 6 : 4; };  // (5 : 8 spills the Y waves at 256 columns)
+#ifndef TAMF_CLIP_XSUB_N2  // (build-time knobs of the A/B runs)
+#define TAMF_CLIP_XSUB_N2 4
+#endif
+#ifndef TAMF_CLIP_XSUB_N4
+#define TAMF_CLIP_XSUB_N4 6
+#endif
+template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? TAMF_CLIP_XSUB_N4 : TAMF_CLIP_XSUB_N2; };  // (5 : 8 spills the Y waves at 256 columns)
 template <class Op, int NI, class Epi>
 struct ClipLaunch {
   static constexpr int XSUB = ClipXsub<NI>::value;
@@ -311,7 +317,7 @@ struct ClipLaunch {
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? (g_krot >> 12) & 7 : 0};
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 1) << 4) : 0};
     const int cus = g_wg_slots / 2;
     hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
@@ -363,6 +369,9 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiQK<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiVt<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -844,8 +853,20 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     const LayerW& w = ctx->layers[l];
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
-      EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
-      HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      // clip tiles of 128 columns = one head of Q, K or V: the Q and K columns as one launch (8 tiles per clip), the V columns
+      // as a second one with the MFMA operands exchanged (V^T rows straight from the accumulators); else the 128 x 128 tiles
+      // (f32: 179 against 190 us at B = 64; the 16-bit modes: 70 against 63 us, they stay on the 128 x 128 tiles; 128 = force)
+      if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128 && ClipLaunch<Op, 2, EpiQK<Op>>::applies(B, Sp, 2 * d, d) &&
+          ClipLaunch<Op, 2, EpiVt<Op>>::applies(B, Sp, d, d)) {
+        EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE};
+        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+        const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
+        EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE};
+        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
+      } else {
+        EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
+        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+      }
       mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
@@ -871,7 +892,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
-      if (!(g_sel & 8) && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
+      if ((g_sel & 32) && ClipLaunch<Op, 2, EpiBiasAct<Op>>::applies(B, Sp, ff, d))  // A/B: 128-column tiles (half the bytes per store burst)
+        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+      else if (!(g_sel & 8) && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
         HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
       else
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
@@ -1412,7 +1435,7 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..23: kernel-selection overrides
-  g_sel = krot >= 0 ? (krot >> 20) & 0xFF : 0;
+  g_sel = krot >= 0 ? (krot >> 20) & 0x3FF : 0;
   g_krot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
   return 0;
 }
