@@ -158,6 +158,7 @@ struct EpiBiasAct {
   // register form: a lane stores 16 bytes per instruction - 4 columns of a 4-byte output, 8 of a 16-bit plane
   static constexpr int LANE_CHUNK = OutOp::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
+  static constexpr int CHUNK_STORES = OutOp::SPLIT ? 2 : 1;  // global store instructions of one finish_act<LANE_CHUNK>
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
 #pragma unroll
@@ -178,6 +179,7 @@ struct EpiQK {
   int act;  // (ACT_NONE; the register epilogue dispatches on it)
   static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
+  static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;
   template <int N>
   TAMF_DEV void finish_act(int, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
     const float sc = (gn < d) ? qscale : 1.0f;
@@ -196,6 +198,7 @@ struct EpiVt {
   int act;
   static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
   static constexpr bool TRANSPOSED = true;
+  static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;  // (of one store_keys)
   // feature eg (column of the V block) of clip b: N stored key positions from pos0 (N = 8: one 16-byte piece per 16-bit plane,
   // the keys 4g .. 4g+3 of two consecutive 16-key groups, vt_key_pos; N = 4: four consecutive keys, f32)
   template <int N>
@@ -544,6 +547,7 @@ struct EpiStoreF32 {
   }
   static constexpr int LANE_CHUNK = 4;
   static constexpr bool TRANSPOSED = false;
+  static constexpr int CHUNK_STORES = 1;
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const {
 #pragma unroll

@@ -228,13 +228,13 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
 
 // Register epilogue of one wave: row tile mi of the wave -> row row0 + 16 mi of the clip; chunk c of the lane = columns
 // gn + 4 CH c .. + CH (column tile c for CH = 4, column tiles 2c and 2c + 1 for CH = 8)
-template <class C, int NI, int MS, int ACT, bool ONE_ROW_TILE = false, class Epi>
+template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
                                   const float (&bi)[C::NCHUNK][C::CHUNK]) {
   constexpr int CH = C::CHUNK;
 #pragma unroll
   for (int mi = 0; mi < MS; ++mi) {
-    const int r = ONE_ROW_TILE ? row0 : row0 + mi * 16;
+    const int r = row0 + mi * 16;
     if (r < Sp) {
 #pragma unroll
       for (int c = 0; c < C::NCHUNK; ++c) {
@@ -253,7 +253,8 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
 // lane: NI ds_write_b128 + NI ds_read_b128, conflict-free, no barrier), selected by a scalar branch.
 template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                                     const float (&bi)[C::NCHUNK][C::CHUNK], char* slot /* wave scratch + 16 * lane */) {
+                                     const float (&bi)[C::NCHUNK][C::CHUNK], char* slot /* wave scratch + 16 * lane */,
+                                     bool one_row = false) {
   constexpr int CH = C::CHUNK;
 #pragma clang loop unroll(disable)
   for (int mi = 0; mi < MS; ++mi) {
@@ -265,7 +266,7 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
       }
     f32x4 a[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) a[ni] = *(const volatile f32x4*)(slot + ni * 1024);
+    for (int ni = 0; ni < NI; ++ni) a[ni] = *(const f32x4*)(slot + ni * 1024);
     const int r = row0 + mi * 16;
     if (r < Sp) {
 #pragma unroll
@@ -273,7 +274,7 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
         float v[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) v[j] = a[c * (CH / 4) + j / 4][j % 4];
-        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c]);
+        epi.template finish_act<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c]);
       }
     }
   }
@@ -281,20 +282,9 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
 template <class C, int NI, int MS, class Epi>
 TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
                               const float (&bi)[C::NCHUNK][C::CHUNK], int abl, char* slot) {
-  if (abl & 24) {  // (benchmark ablations)
-    if (abl & 16) { Sp = 0x7fffffff; m0 = 0; row0 &= 15; }
-    if (abl & 16) {
-      f32x4 a1[C::MSUB0][NI];
-#pragma unroll
-      for (int mi = 0; mi < MS; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) a1[mi][ni] = acc[mi][ni];
-      // rows of the first row tile only: the same lines again and again
-      if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_act<C, NI, MS, ACT_GELU, true>(epi, a1, row0, Sp, m0, gn, bi);
-      else clip_store_rows_act<C, NI, MS, ACT_NONE, true>(epi, a1, row0, Sp, m0, gn, bi);
-    } else {
-      clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi);
-    }
+  if (abl & 24) {  // (benchmark ablations: 8 = no activation, 16 = every row of the tile is stored into the clip's first row)
+    if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, (abl & 16) != 0);
+    else clip_store_rows_rolled<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, slot, (abl & 16) != 0);
     return;
   }
   if (epi.act == ACT_GELU) {
@@ -467,11 +457,23 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
                               c0, c1, acc);
 #endif
       if (is.live && !pre) is.advance(ga, KT, ntn, nq, prow, pch);
+      // K tile j + 1 has landed: everything but what was issued behind it (vmcnt retires in order).  In a tile's first interval
+      // that is this interval's requests AND the SX stores of the previous tile's rows, which went out behind them: the wait must
+      // not cover those - a store is acknowledged when the L2 has taken it, and the 256 CUs store their tiles at the same moment.
+      constexpr int SX = TR ? ((C::MSUBX + (Op::PREC == 0 ? 0 : 1)) / (Op::PREC == 0 ? 1 : 2)) * NI * Epi::CHUNK_STORES
+                            : C::MSUBX * C::NCHUNK * Epi::CHUNK_STORES;
+      constexpr int PH = C::PIECES_HI;
+      static_assert(PH + SX < 64, "vmcnt range");
+      const bool behind = pre && !(ga.abl & 4);  // the stores are there
       pre = false;
-      // K tile j + 1 has landed: everything but the requests issued behind it (vmcnt retires in order; in a tile's first interval
-      // the epilogue's loads and stores sit behind this interval's requests, and the wait covers those too - it is a long interval)
       if (LA == 2 && batch) {
-        if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
+        if (behind) {
+          if (nq < C::PIECES_REM) clip_wait_vm<PH + SX>(); else clip_wait_vm<PH - 1 + SX>();
+        } else {
+          if (nq < C::PIECES_REM) clip_wait_vm<PH>(); else clip_wait_vm<PH - 1>();
+        }
+      } else if (LA == 1 && behind) {
+        clip_wait_vm<SX>();
       } else {
         clip_wait_vm<0>();
       }
@@ -490,7 +492,10 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           for (int ni = 0; ni < NI; ++ni) bb[ni] = epi.bias[n0 + wn0 + lr + 16 * ni];
         } else {
 #pragma unroll
-          for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+          for (int c = 0; c < C::NCHUNK; ++c) {
+            if (ga.abl & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+          }
         }
         if (is.live && !(ga.abl & 1)) {
           clip_issue<Op, C>(ga, is.s, nq, prow, is.kti, smem + sn * C::STAGE);
@@ -549,7 +554,10 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         } else {
           float bi[C::NCHUNK][C::CHUNK];
 #pragma unroll
-          for (int c = 0; c < C::NCHUNK; ++c) epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+          for (int c = 0; c < C::NCHUNK; ++c) {
+            if (ga.abl & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
+          }
           clip_settle(bi);
           if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, ga.abl, slot);
         }

@@ -317,7 +317,7 @@ struct ClipLaunch {
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 1) << 4) : 0};
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
     const int cus = g_wg_slots / 2;
     hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
@@ -1313,12 +1313,13 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       e = gemm128<Op>(ga, ep, st);
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
-      if (g_krot >= 0 && (g_krot & 0x8000)) ep.ldo = 0;   // ablation: every row stores to the same (L2-resident) row - no HBM writes
-      if (g_krot >= 0 && (g_krot & 0x20000)) ep.act = ACT_NONE;  // ablation: no GELU
-      if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(M / 208, 208, N, K))
-        e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
-      else
+      if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(M / 208, 208, N, K)) {
+        e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);  // (ablations: ClipGemmArgs::abl)
+      } else {
+        if (g_krot >= 0 && (g_krot & 0x20000)) ep.ldo = 0;  // ablation: every row stores to the same (L2-resident) row - no HBM writes
+        if (g_krot >= 0 && (g_krot & 0x8000)) ep.act = ACT_NONE;  // ablation: no GELU
         e = gemm128<Op>(ga, ep, st);
+      }
     }
   }
   (void)hipEventRecord(e1, st);
