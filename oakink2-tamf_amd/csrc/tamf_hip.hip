@@ -202,7 +202,7 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
-// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles
+// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -283,9 +283,11 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 // Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip.  Used when the clip has 13 MFMA row tiles (193..208 padded
 // rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
 // else runs on the 128 x 128 tiles.
-// row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the 13 row tiles
+// row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the 13 row tiles - 6 of 13 at
+// 256 columns (5 : 8 spills the Y waves), 2 of 13 at 128 columns (a loader wave is blocked ~850 of the ~1 900 cycles of a 128-column
+// interval while its 11 pieces queue; FFN2 at B = 64: 73.7 us with 4 : 9, 69.5 us with 2 : 11)
 #ifndef TAMF_CLIP_XSUB_N2  // (build-time knobs of the A/B runs)
-#define TAMF_CLIP_XSUB_N2 4
+#define TAMF_CLIP_XSUB_N2 2
 #endif
 #ifndef TAMF_CLIP_XSUB_N4
 #define TAMF_CLIP_XSUB_N4 6
@@ -906,7 +908,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // through every CU), and in f32 when the clip tiles apply (64 x 512 f32 tiles reach 75 TFLOP/s, the clip tiles 113: 362 ->
       // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
       // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
-      const bool clip2 = (Op::SPLIT || Op::PREC == 0) && !(g_sel & 2) && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
+      const bool clip2 = (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2) && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff);
       if ((Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
