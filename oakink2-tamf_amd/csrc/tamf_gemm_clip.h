@@ -1,4 +1,5 @@
-// Clip-aligned GEMM for the FFN GEMMs of the encoder layers (FFN1: 256-column tiles, FFN2: 128-column tiles):
+// Clip-aligned GEMM of the encoder layers (FFN1: 256-column tiles; FFN2, and in f32 out-proj and the QKV projection: 128-column
+// tiles):
 //
 //   C[b*Sp + r][n] = sum_k A[b*Sp + r][k] * W[n][k]          one M tile = the Sp token rows of ONE clip
 //
@@ -8,31 +9,44 @@
 // matrix pipe.  And M = 64 clips * 208 rows = 13 * 2^10 rows never fills 256 CUs evenly with power-of-two row tiles (every
 // launch ends in a 3.25th round).  A tile of one whole clip (208 rows = 13 MFMA row tiles) by 256 / 128 columns stages
 // (208 + BN) * 128 bytes per K tile for 208 * BN outputs - 1.8x / 1.25x the flops per staged byte - and B = 64 clips give
-// 512 / 256 tiles: exact rounds of the 256 CUs.  (Measured against the small tiles at B = 64, f16x3, in situ: FFN1 78.7
-// against 86.4 us, FFN2 even; the QKV projection with 192-column tiles and its V^T epilogue lost - 72 against 63 us - and
-// stays on the 128 x 128 tiles.)
+// 512 / 256 tiles: exact rounds of the 256 CUs.
 //
 // Workgroup = 8 waves (one workgroup per CU, two waves per SIMD), wave grid 2 (M) x 4 (N): waves 0-3 ("X") own the first
 // XSUB row tiles, waves 4-7 ("Y") the other 13 - XSUB (waves w and w + 4 share a SIMD, so every SIMD carries all 13), each
 // over BN / 4 columns.  Staging, swizzle, fragment addressing and the MFMA operand traits are those of tamf_gemm.h (LDS-DMA
-// pieces of 8 rows x 128 bytes, source-side XOR swizzle, double-buffered stages, one barrier per K tile).
+// pieces of 8 rows x 128 bytes, source-side XOR swizzle, one barrier per K tile).
 //
 // The two waves of a SIMD run half a K tile apart.  Right after a barrier every wave would wait for its first fragments
-// (LDS latency) and then issue its share of the next K tile's 58 LDS-DMA pieces (the CU's address unit takes 16 cycles per
+// (LDS latency) and then issue its share of the next K tile's LDS-DMA pieces (the CU's address unit takes 16 cycles per
 // piece and a wave is blocked while its piece queues) - with all eight waves in those phases together the matrix pipe idles
-// for a third of each K tile (measured with the ablation bits of tools/kbench.py: fragment reads + barriers 1 180 cycles,
-// MFMAs 2 500, loads 700 per K tile, and the three ADD UP; QKV 76.8 us against 64.2 us on the small tiles, whose two
-// independent workgroups per CU cover each other).  So the waves of M half 0 ("X": waves 0-3) work as above - fragments of
-// K tile i, all DMA pieces of K tile i + 1, MFMAs of K tile i - while their SIMD partners ("Y": waves 4-7) spend the head of
-// the interval on the MFMAs of K tile i - 1, whose fragments they read into registers at the end of the previous interval,
-// and its tail on reading the fragments of K tile i.  The matrix pipe of every SIMD is fed by Y while X waits and issues, and
-// by X while Y reads.  Y issues its MFMAs at static priority and X, which carries the DMA issue, owns fewer of the 13 row
-// tiles (XSUB = 6 at 256 columns - 5 : 8 would spill Y's fragment registers - and 4 at 128 columns).  Per-wave shader-clock
-// stamps (tools/clip_timeline.py, -DTAMF_TIMELINE) at 256 columns: the matrix pipe is busy 2 744 of the 3 020 cycles of a
-// K-tile interval (156 MFMAs at 17.6 cycles), the loads are hidden completely.
+// for a third of each K tile.  So the X waves work as above - fragments of K tile i, all DMA pieces of a later K tile, MFMAs
+// of K tile i - while their SIMD partners, the Y waves, spend the head of the interval on the MFMAs of K tile i - 1, whose
+// fragments they read into registers at the end of the previous interval, and its tail on reading the fragments of K tile i.
+// The matrix pipe of every SIMD is fed by Y while X waits and issues, and by X while Y reads.  Y issues its MFMAs at static
+// priority and X, which carries the DMA issue, owns fewer of the 13 row tiles (6 at 256 columns, 2 at 128: tamf_hip.hip).
 //
-// Workgroups are persistent over their tiles.  The accumulators are parked in LDS in slabs of 64 rows and handed to the same
-// row-wise epilogue functors as the other GEMMs (their stores drain behind the next slab and the next tile's first K tiles).
+// Round-2 additions, each from a measurement on MI355X (tools/clip_timeline*.py: per-wave shader-clock stamps, standalone and
+// inside the hipGraph step; tools/kbench.py ablation bits; tools/ab_*.sh: two builds alternating on one box):
+//  * Inside the step the 128-column K loop waited for its LDS-DMA (interval 2 172 cycles standalone, 2 804 in situ: the A panel
+//    of FFN2 comes from the Infinity Cache / HBM, the loader waves sat 1 020 cycles at the barrier).  Its stage is 42 KB, so there
+//    are THREE stages and a K tile is requested two intervals ahead; the loaders wait with a counted vmcnt (everything but the
+//    newest requests) instead of vmcnt(0).  FFN2 in situ 85 -> 73 us.
+//  * A workgroup's tiles are one stream of K tiles: no drain between tiles, the next tile's requests go out before the
+//    epilogue of the finished one.
+//  * The epilogue goes from the accumulators to HBM: W rows are staged in a permuted order (clip_wperm) so that a lane owns
+//    16-byte pieces of its output row.  No LDS round trip of the fp32 tile, no barrier; X stores its rows at the head of the
+//    next tile's first interval while Y multiplies the last K tile, Y behind those MFMAs while X is back in the K loop; the
+//    loaders' boundary wait leaves their own stores in flight (a store is acknowledged when the L2 has taken it, and all CUs
+//    store at the same moment).
+//  * Epilogues with an activation run their row tiles in a LOOP (lane-private LDS slot): unrolled, GELU is 11 - 13 KB of
+//    straight-line code per wave role that every launch fetched cold - +3 us per FFN1 launch inside the step, invisible in a
+//    standalone benchmark loop.
+//  * The hi / lo split of an operand store is compiled with fp contraction off: fused with the multiply that produced the
+//    value it stored different lo words in different kernel variants (batch-invariance tests).
+// What did NOT pay (measured, reverted): the pieces of a K tile spread between the loaders' MFMAs (FFN2 72 -> 85 us), Y's
+// fragment reads fused under its MFMAs (69 -> 76 us, or spills), erf from an LDS table instead of v_exp / v_rcp (the gather's
+// bank conflicts cost more than the transcendentals), 128-column tiles for FFN1 (86 against 83 us), QKV on clip tiles in the
+// 16-bit modes (two launches, 70 against 63 us).
 #pragma once
 #include "tamf_gemm.h"
 

@@ -26,7 +26,7 @@ PY
   python3 - $out $dt <<'PY'
 import csv, glob, json, sys, collections
 out, dt = sys.argv[1:3]
-CLASSES = [("EpiQKV", "gemm_qkv"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
+CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
            ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
 SPLIT = dt in ("bf16x3", "f16x3")  # split modes: every EpiLN launch is the out-proj; the others alternate out-proj / FFN2 per layer
 def per_launch(ctr):
