@@ -369,17 +369,30 @@ struct EpiLN {
         v[j] = (cp[j] + bi[j]) + rs[i][j];
         s += v[j];
       }
-      const float mean = wave_sum(s) * (1.0f / BN);
-      float q = 0.f;
+      float mean, var;
+      if constexpr (VPL == 8) {  // 512 columns: the association order shared with the clip-tile LayerNorm (ln_row_sum512)
+#pragma clang fp contract(off)
+        mean = ln_row_sum512(v) * (1.0f / BN);
+        float dq[VPL];
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const float dlt = v[j] - mean;
-        q += dlt * dlt;
+        for (int j = 0; j < VPL; ++j) {
+          const float dlt = v[j] - mean;
+          dq[j] = dlt * dlt;
+        }
+        var = ln_row_sum512(dq) * (1.0f / BN);
+      } else {
+        mean = wave_sum(s) * (1.0f / BN);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const float dlt = v[j] - mean;
+          q += dlt * dlt;
+        }
+        var = wave_sum(q) * (1.0f / BN);
       }
-      const float var = wave_sum(q) * (1.0f / BN);
       const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * ga[j] + be[j];
+      for (int j = 0; j < VPL; ++j) v[j] = fmaf((v[j] - mean) * rstd, ga[j], be[j]);  // (explicit: the same in every LayerNorm)
       float* op = xout + (long)gr * BN + c0;
       if constexpr (VPL == 8) {
         gst16f(op, v[0], v[1], v[2], v[3]);

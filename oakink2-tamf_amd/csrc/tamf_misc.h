@@ -116,16 +116,30 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
     v[j] = c[(long)row * D + c0 + j] + resid[(long)row * D + c0 + j];
     s += v[j];
   }
-  const float mean = wave_sum(s) * (1.0f / D);
-  float q = 0.f;
+  float mean, var;
+  if constexpr (VPL == 8) {  // 512 columns: the association order shared with the clip-tile LayerNorm (ln_row_sum512)
+#pragma clang fp contract(off)
+    mean = ln_row_sum512(v) * (1.0f / D);
+    float dq[VPL];
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const float dl = v[j] - mean;
-    q += dl * dl;
+    for (int j = 0; j < VPL; ++j) {
+      const float dl = v[j] - mean;
+      dq[j] = dl * dl;
+    }
+    var = ln_row_sum512(dq) * (1.0f / D);
+  } else {
+    mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const float dl = v[j] - mean;
+      q += dl * dl;
+    }
+    var = wave_sum(q) * (1.0f / D);
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+  const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+  for (int j = 0; j < VPL; ++j) v[j] = fmaf((v[j] - mean) * rstd, gamma[c0 + j], beta[c0 + j]);  // (explicit: the same in every LayerNorm)
   if constexpr (VPL % 4 == 0) {
 #pragma unroll
     for (int j = 0; j < VPL; j += 4) gst16f(xout + (long)row * D + c0 + j, v[j], v[j + 1], v[j + 2], v[j + 3]);
