@@ -202,7 +202,8 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
-// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too
+// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too,
+// 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -313,7 +314,7 @@ struct ClipLaunch {
     const int KT = (K * Op::EB) / GEMM_BKB;
     if (KT < 2 || (KT & 1)) return false;
     const int cus = g_wg_slots / 2, tiles = n_clips * (N / C::BN), rounds = (tiles + cus - 1) / cus;
-    return tiles * 100 >= rounds * cus * 74;  // >= 74 % of the workgroup slots of its rounds are used
+    return tiles * 100 >= rounds * cus * ((g_sel & 1024) ? 50 : 74);  // >= 74 % of the workgroup slots of its rounds are used (A/B: 50 %)
   }
   static hipError_t launch(const Op*, const typename Op::elem_t* A, int lda, const typename Op::elem_t* W, int ldw, int n_clips,
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
@@ -1438,7 +1439,7 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..23: kernel-selection overrides
-  g_sel = krot >= 0 ? (krot >> 20) & 0x3FF : 0;
+  g_sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
   g_krot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
   return 0;
 }
