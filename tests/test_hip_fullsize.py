@@ -216,3 +216,36 @@ def test_forward_clip_tiles_with_padded_rows(prec):
     print(f"padded-rows forward[{prec}] B=48 T=190: max|err| = {err:.3e}")
     assert err < FWD_TOL[prec], (prec, err)
     ctx.close()
+
+
+# selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
+# one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
+SELECTIONS = {
+    0x001: "no clip tiles at all (128 x 128 / LayerNorm-fused tiles everywhere)",
+    0x002: "FFN2 / out-proj not on clip tiles",
+    0x008: "FFN1 on the 128 x 128 tiles",
+    0x010: "out-proj as clip GEMM + LayerNorm kernel",
+    0x020: "FFN1 on 128-column clip tiles",
+    0x040: "QKV on the 128 x 128 tiles (f32 default: clip tiles)",
+    0x080: "QKV as two clip launches (Q|K, V transposed)",
+    0x100: "FFN2 as clip GEMM + LayerNorm kernel (bf16 default: fused)",
+    0x400: "clip tiles from 50 % utilisation",
+}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_kernel_selections_give_the_same_bits(full, prec):
+    from oakink2_tamf_amd.hip_backend import lib
+
+    B = 48  # (1.5 rounds of clip tiles for FFN2: remainders too)
+    ctx = _make_ctx(full["arch"], full["sd"], B, T_FULL, prec)
+    _set_cond(ctx, _sub(full["cond"], slice(0, B)))
+    try:
+        ref = ctx.denoise(full["x"][:B], full["t"][:B]).cpu()
+        for sel, what in SELECTIONS.items():
+            lib().tamf_set_gemm_tuning((sel << 20) | 0xFFFFF)
+            got = ctx.denoise(full["x"][:B], full["t"][:B]).cpu()
+            assert torch.equal(got, ref), (prec, hex(sel), what, float((got - ref).abs().max()))
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+        ctx.close()
