@@ -374,6 +374,7 @@ static hipError_t prepare_all() {
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiQK<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 4, EpiQK<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiVt<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
@@ -858,11 +859,14 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
       // clip tiles of 128 columns = one head of Q, K or V: the Q and K columns as one launch (8 tiles per clip), the V columns
       // as a second one with the MFMA operands exchanged (V^T rows straight from the accumulators); else the 128 x 128 tiles
-      // (f32: 179 against 190 us at B = 64; the 16-bit modes: 70 against 63 us, they stay on the 128 x 128 tiles; 128 = force)
+      // (f32: 174.5 against 190 us at B = 64; the 16-bit modes: 62.5 against 62 us, they stay on the 128 x 128 tiles; 128 = force)
       if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128 && ClipLaunch<Op, 2, EpiQK<Op>>::applies(B, Sp, 2 * d, d) &&
           ClipLaunch<Op, 2, EpiVt<Op>>::applies(B, Sp, d, d)) {
         EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE};
-        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+        if (ClipLaunch<Op, 4, EpiQK<Op>>::applies(B, Sp, 2 * d, d))  // the Q | K columns on 256-column tiles where they fill their rounds (f32, B = 64: 174.5 against 179 us)
+          HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+        else
+          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
         const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
         EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE};
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
