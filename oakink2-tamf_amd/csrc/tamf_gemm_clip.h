@@ -46,7 +46,8 @@
 // What did NOT pay (measured, reverted): the pieces of a K tile spread between the loaders' MFMAs (FFN2 72 -> 85 us), Y's
 // fragment reads fused under its MFMAs (69 -> 76 us, or spills), erf from an LDS table instead of v_exp / v_rcp (the gather's
 // bank conflicts cost more than the transcendentals), 128-column tiles for FFN1 (86 against 83 us), QKV on clip tiles in the
-// 16-bit modes (two launches, 70 against 63 us).
+// 16-bit modes (two launches - Q | K on 256-column tiles, V transposed on 128-column ones: 62.5 against 62 us; used in f32, where it
+// wins), LayerNorm inside the FFN2 kernel.
 #pragma once
 #include "tamf_gemm.h"
 
