@@ -1,4 +1,5 @@
-"""GPU: ms per DDPM step of the hipGraph loop (B=64, T=196 by default), repeated: loop_time.py [prec] [B] [ddpm_steps] [reps]"""
+"""GPU: ms per DDPM step of the hipGraph loop (B=64, T=196 by default), repeated: loop_time.py [prec] [B] [ddpm_steps] [reps] [tuning]
+(tuning = tamf_set_gemm_tuning value the graph is captured under, e.g. 0x400fffff)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
@@ -9,6 +10,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+tune = int(sys.argv[5], 0) if len(sys.argv) > 5 else -1
 T = 196
 arch = dict(latent_dim=512, ff_size=2048, num_layers=8, num_heads=4)
 sd = O.det_state_dict(O.ARCH_MDM_L, tag="bench/w")
@@ -20,8 +22,11 @@ cond = O.det_cond(B, T, tag="x", arch=O.ARCH_MDM_L)
 cd = {k: (v.cuda() if hasattr(v, "cuda") else v) for k, v in cond.items()}
 ctx.set_cond(cd["text_embedding"], cd["hand_side"], cd["shape"], cd["obj_embedding"], cd["obj_traj"])
 out = torch.empty(B, 99, 1, T, device="cuda")
+if tune != -1:
+    from oakink2_tamf_amd.hip_backend import lib
+    lib().tamf_set_gemm_tuning(tune)
 ctx.sample_loop(seed=1, out=out); torch.cuda.synchronize()
 ts = []
 for r in range(reps):
     t = time.perf_counter(); ctx.sample_loop(seed=2 + r, out=out); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / N * 1e3)
-print(f"{os.environ.get('TAMF_LIB_OVERRIDE', 'default').split('/')[-1]} {prec} B={B}: ms/step " + " ".join(f"{t:.3f}" for t in ts), flush=True)
+print(f"{os.environ.get('TAMF_LIB_OVERRIDE', 'default').split('/')[-1]} {prec} B={B} tuning {tune}: ms/step " + " ".join(f"{t:.3f}" for t in ts), flush=True)
