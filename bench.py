@@ -49,7 +49,9 @@ CONFIGS = {
     3: dict(batch=32, dtype=None, label="BASELINE.json configs[2]: arch_mdm_l B=256 T=196 1000-step DDPM sharded over 8 GPUs (32 clips per GPU)"),
     5: dict(batch=64, dtype="bf16", label="BASELINE.json configs[4]: arch_mdm_l bf16 B=512 T=196 hipGraph 1000-step loop over 8 GPUs (64 clips per GPU)"),
 }
-DEFAULT_DTYPE = "f16x3"
+DEFAULT_DTYPE = "f16x3"  # = oakink2_tamf_amd.hip_backend.DEFAULT_PRECISION (asserted in main): one default everywhere
+# in-run parity gates (max abs error of one denoiser evaluation vs the oracle, outputs O(1)): the gates of tests/test_hip_forward.py
+CHECK_TOL = {"f32": 1e-5, "f16x3": 1e-5, "bf16x3": 6e-5, "bf16": 3e-2}
 
 
 def flops_per_clip_step(arch, T):
@@ -60,19 +62,22 @@ def flops_per_clip_step(arch, T):
 
 
 def hbm_traffic(dtype, kernel, B, T):
-    """HBM-side bytes per launch of `kernel` from the committed PMC measurement of this exact workload
+    """(bytes per launch, source) of `kernel` from the committed PMC measurement of this exact workload
     (profiles/rNN/hbm_traffic_<dtype>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
-    per the gfx950 correction of MI355X_MICROARCH.md).  Newest round first; None when no measurement matches."""
+    per the gfx950 correction of MI355X_MICROARCH.md).  The counters cannot be collected inside a timed run (they need
+    the profiler's own passes), so the value is NOT measured by this process: `source` names the file and the commit the
+    counters were taken at.  Newest round first; (None, None) when no measurement matches."""
     pdir = os.path.join(ROOT, "profiles")
     for rnd in sorted((d for d in os.listdir(pdir) if d.startswith("r")), reverse=True) if os.path.isdir(pdir) else []:
         try:
-            with open(os.path.join(pdir, rnd, f"hbm_traffic_{dtype}.json")) as f:
+            rel = os.path.join("profiles", rnd, f"hbm_traffic_{dtype}.json")
+            with open(os.path.join(ROOT, rel)) as f:
                 m = json.load(f)
             if m.get("B") == B and m.get("T") == T and kernel in m["kernels"]:
-                return m["kernels"][kernel]["traffic_bytes_per_launch"]
+                return m["kernels"][kernel]["traffic_bytes_per_launch"], f"{rel}@{m.get('commit', 'unstamped')}"
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def usable_cores() -> int:
@@ -187,6 +192,9 @@ class HipSampler:
     def step_profile(self):
         return self.ctx.step_profile()
 
+    def status_flags(self):
+        return self.ctx.status_flags(clear=True)
+
     @property
     def kernels_per_step(self):
         return self.ctx.step_kernel_count
@@ -203,9 +211,11 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, poll_s=0.2, grace_s=10.0):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not initialised the
-    GPU and never will), wait for them, exit with the worst return code.  Rank 0's stdout is the JSON line."""
+    GPU and never will) and watch them.  Rank 0's stdout is the JSON line.  When a rank exits non-zero its siblings - which
+    would otherwise sit in the process-group set-up or a collective until the RCCL timeout - are terminated (SIGTERM, then
+    SIGKILL after `grace_s`) and that rank's code is returned; otherwise 0 once all have finished."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -213,9 +223,27 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        time.sleep(poll_s)
+    failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+    print(f"bench.py: rank(s) {failed} exited with {rc}; terminating the other ranks", file=sys.stderr, flush=True)
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        if p.poll() is None:
+            p.terminate()
+    t_end = time.monotonic() + grace_s
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
@@ -237,8 +265,11 @@ def parse_args(argv):
     ap.add_argument("--also", default=None,
                     help="comma list of extra dtypes measured with 1 loop each on 1 GPU (other_dtypes); default: all other modes; '' = none")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU test of the launch/gather path (needs --sampler)")
-    ap.add_argument("--sampler", default=None, help="test hook: module:callable replacing the HIP sampler (tests/bench_stub.py); never set on a GPU run")
+    ap.add_argument("--sampler", default=None, help="test hook (only with --backend gloo): module:callable replacing the HIP sampler (tests/bench_stub.py)")
+    ap.add_argument("--fp32-loops", type=int, default=3, help="timed loops of the strict-fp32 entry of the line (N = 1 only; 0 = off)")
     args = ap.parse_args(argv)
+    if args.sampler and args.backend != "gloo":
+        ap.error("--sampler is the CPU test hook of the launch / gather path: it needs --backend gloo")
     preset = CONFIGS[args.config]
     if args.batch is None:
         args.batch = preset["batch"]
@@ -292,6 +323,11 @@ def main(argv=None, sampler_factory=None):
     from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
 
     factory = sampler_factory or HipSampler
+    rc = 0
+    if not stub:
+        from oakink2_tamf_amd.hip_backend import DEFAULT_PRECISION
+
+        assert DEFAULT_DTYPE == DEFAULT_PRECISION, "bench.py and the package must share one default precision"
     arch = ARCHS[args.arch]
     B, T, N = args.batch, args.frames, args.ddpm_steps
     # random-init weights of the named architecture (PyTorch default initialisers, fixed seed; identical on all ranks)
@@ -335,6 +371,10 @@ def main(argv=None, sampler_factory=None):
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     finite = bool(torch.isfinite(res).all().item())
+    # range guard of the split-fp16 mode: sticky device flag raised by any operand store beyond +-65504 during the loops above
+    range_flags = {}
+    if not stub and args.dtype == "f16x3":
+        range_flags[args.dtype] = bool(sampler.status_flags() & 1)
     # what every rank sampled, as seen by the collective (printed by rank 0)
     rank_info = {"rank": rank, "clips": [clip0, clip0 + B], "device": str(dev)}
     if world > 1:
@@ -391,11 +431,12 @@ def main(argv=None, sampler_factory=None):
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": dom["tflops"] / peak,
-            "traffic": hbm_traffic(dtype, dom["kernel"], B, T),
+            "traffic": hbm_traffic(dtype, dom["kernel"], B, T)[0],
+            "traffic_source": hbm_traffic(dtype, dom["kernel"], B, T)[1],
             "avg_launch_ms": dom["avg_ms"],
             "share_of_step": dom["share"],
             "attention": next(({"avg_launch_ms": r["avg_ms"], "tflops": r["tflops"], "frac": r["tflops"] / peak,
-                               "traffic": hbm_traffic(dtype, "attention", B, T)}
+                               "traffic": hbm_traffic(dtype, "attention", B, T)[0]}
                               for r in prof_rows if r["kernel"].startswith("attention")), None),
         }
 
@@ -404,22 +445,33 @@ def main(argv=None, sampler_factory=None):
         sampler.set_cond(cond_dev)
         roofline = roofline_of(sampler, args.dtype, args.profile_out)
 
-    # the other arithmetic modes: one warm-up + one timed loop each on rank 0's shard only (context, not the headline)
+    # the other arithmetic modes on rank 0's shard (context, not the headline): one warm-up loop, then `fp32-loops` timed loops
+    # for f32 - the reference's own arithmetic, reported as the top-level "fp32" entry - and one for the rest; every mode
+    # reported gets its own finiteness test, oracle check and dominant-kernel roofline
     other = {}
+    finite_by = {args.dtype: finite}
     if rank == 0 and world == 1 and not stub:
-        for dt in [d for d in args.also.split(",") if d and d != args.dtype]:
+        extra = [d for d in args.also.split(",") if d and d != args.dtype]
+        if args.fp32_loops > 0 and args.dtype != "f32" and "f32" not in extra:
+            extra.append("f32")
+        for dt in extra:
+            loops = max(1, args.fp32_loops) if dt == "f32" else 1
             s2 = HipSampler(arch, sd, B, T, N, dt, dev, tab)
             s2.set_cond(cond_dev)
             s2.sample(1, clip0, out)
             sync()
             t1 = time.perf_counter()
-            s2.sample(2, clip0, out)
+            for k in range(loops):
+                s2.sample(2 + k, clip0, out)
             sync()
-            dt_s = time.perf_counter() - t1
+            dt_s = (time.perf_counter() - t1) / loops
+            finite_by[dt] = bool(torch.isfinite(out).all().item())
+            if dt == "f16x3":
+                range_flags[dt] = bool(s2.status_flags() & 1)
             tf = flops_per_clip_step(arch, T) * B * N / dt_s / 1e12
             other[dt] = {"value": B * T / dt_s, "unit": "frames/s", "ms_per_ddpm_step": dt_s / N * 1e3,
-                         "whole_path_tflops": tf, "whole_path_frac_of_peak": tf / PEAK_TFLOPS[dt],
-                         "note": "same workload, 1 timed loop after 1 warm-up loop"}
+                         "whole_path_tflops": tf, "whole_path_frac_of_peak": tf / PEAK_TFLOPS[dt], "finite": finite_by[dt],
+                         "timed_loops": loops, "note": f"same workload, {loops} timed loop(s) after 1 warm-up loop"}
             if check_in is not None:
                 xc, tc, ref, nc = check_in
                 check[dt] = float((s2.denoise(xc.to(dev), tc.to(dev))[:nc].cpu() - ref).abs().max())
@@ -464,20 +516,40 @@ def main(argv=None, sampler_factory=None):
             "finite": finite,
             "roofline": roofline,
         }
+        # strict fp32 (the reference's arithmetic, launch/sample.py:173) as a first-class entry of the line
+        if args.dtype == "f32":
+            line["fp32"] = {"value": value, "unit": "frames/s", "ms_per_ddpm_step": line["ms_per_ddpm_step"], "timed_loops": args.steps,
+                            "whole_path_frac_of_peak": line["whole_path_frac_of_peak"], "roofline": roofline, "finite": finite}
+        elif "f32" in other:
+            o = other["f32"]
+            line["fp32"] = {k: o[k] for k in ("value", "unit", "ms_per_ddpm_step", "timed_loops", "whole_path_tflops",
+                                              "whole_path_frac_of_peak", "finite", "roofline")}
+            line["fp32"]["what"] = ("the same workload in the reference's own arithmetic (v_mfma_f32_16x16x4_f32: exact fp32 products, "
+                                    "fp32 accumulate), 1 GPU")
+        ok = all(finite_by.values()) and not any(range_flags.values())
         if check:
-            line["check"] = {"max_abs_err_vs_oracle": check, "what": f"one denoiser evaluation (t={N // 2}) of the first "
+            line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
+                             "what": f"one denoiser evaluation (t={N // 2}) of the first "
                              f"{min(args.check_clips, B)} clips of the bench batch vs oracle.denoiser_forward (fp32 torch-CPU restatement of the reference), outputs O(1)"}
+            ok = ok and all(e == e and e < CHECK_TOL[d] for d, e in check.items())
+        if range_flags:
+            line["f16_range_flag"] = range_flags  # True = an operand left the fp16 range during the timed loops (tamf_get_status_flags)
+        line["finite_by_dtype"] = finite_by
+        line["check_ok"] = ok  # every reported dtype: finite samples, oracle check inside its tolerance, no range flag
         if other:
             line["other_dtypes"] = other
         if not args.no_cpu_baseline and world == 1 and not stub:  # at N = 1 only (one host measurement, not one per scaling point)
             line["cpu_baseline"] = cpu_baseline(args.arch, sd, B, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
+        if not line["check_ok"]:
+            print("bench.py: in-run check FAILED (see check / finite_by_dtype / f16_range_flag in the line)", file=sys.stderr, flush=True)
+            rc = 3
     sampler.close()
     if world > 1:
         dist.barrier()  # rank 0 was still profiling / printing
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

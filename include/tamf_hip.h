@@ -40,8 +40,15 @@ typedef enum tamf_status {
   TAMF_ERR_STATE = -2,     /* call order violated (weights not finalised, cond not set, ...) */
   TAMF_ERR_HIP = -3,       /* a HIP runtime call failed */
   TAMF_ERR_MISSING = -4,   /* a required checkpoint tensor was not loaded */
-  TAMF_ERR_NOMEM = -5
+  TAMF_ERR_NOMEM = -5,
+  TAMF_ERR_RANGE = -6      /* a weight does not fit the operand format of the context's precision (f16x3: |w| > 65504) */
 } tamf_status;
+
+/* bits of tamf_get_status_flags */
+typedef enum tamf_status_flag {
+  TAMF_STATUS_F16_RANGE = 1 /* f16x3 only: an activation beyond +-65504 (or +-inf) was stored as a split-fp16 operand since the
+                               last clear; results computed since then may differ from the reference's fp32 arithmetic */
+} tamf_status_flag;
 
 /* arithmetic mode of the MFMA contractions (everything else - residual stream, LayerNorm, softmax,
  * DDPM state - is float32 in every mode) */
@@ -84,7 +91,8 @@ const char* tamf_last_error(const tamf_ctx* ctx);
  * a known name with a wrong shape is TAMF_ERR_INVALID. */
 int tamf_load_weight(tamf_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 /* Repack into kernel layouts (operand precision, fused input weights, timestep-embedding table for
- * t in [0, max_timesteps)).  Synchronises `stream`.  TAMF_ERR_MISSING names the first absent tensor. */
+ * t in [0, max_timesteps)).  Synchronises `stream`.  TAMF_ERR_MISSING names the first absent tensor;
+ * TAMF_ERR_RANGE (f16x3 only) the first weight with max |w| > 65504 (see tamf_get_status_flags). */
 int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream);
 
 /* float64 tables of GaussianDiffusion.__init__ for the n_steps-step process; they are cast to float32
@@ -174,6 +182,15 @@ int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_
                        int64_t n_points, const double* scale3, const double* translate3, int32_t resolution,
                        double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream);
 
+/* Range guard of the split-fp16 mode.  The reference computes in fp32 (launch/sample.py:173); TAMF_PREC_F16X3 stores every
+ * MFMA operand as two fp16 planes, so a weight or activation beyond +-65504 cannot be represented.  Weights are checked when
+ * they are repacked (tamf_finalize_weights returns TAMF_ERR_RANGE and names the tensor); activations are checked by the kernels
+ * that split them, which raise a sticky bit in a per-device status word.  This call synchronises `stream`, returns the bits
+ * raised on the context's device since the last clear (by any context of this process on that device) in *flags and, with
+ * clear != 0, resets them.  The Python module calls it after every forward / sampling loop and re-runs the call in
+ * TAMF_PREC_F32 when the bit is set (oakink2_tamf_amd/model/interaction_segment_mdm.py). */
+int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t clear, void* stream);
+
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
 int tamf_step_kernel_count(const tamf_ctx* ctx);
 /* hipGraph bookkeeping of the sampling loop: how often a step sequence has been captured + instantiated on this context
@@ -209,7 +226,9 @@ int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t 
  * K-loop rotation, L2 touch-prefetch distance, ablation flags). */
 int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                     int32_t iters, float* ms_out, void* stream);
-/* Override the GEMM tuning bits for every subsequent launch (-1 restores the per-kernel defaults). */
+/* Override the GEMM tuning / kernel-selection bits for every subsequent launch (-1 restores the per-kernel defaults); process-global;
+ * retires the captured loop graphs of all live contexts so that the next tamf_sample_loop re-captures with the new selection.
+ * The ablation bits (no loads / no MFMAs / no epilogue) only exist in -DTAMF_BENCH builds of the library. */
 int tamf_set_gemm_tuning(int32_t krot);
 
 #ifdef __cplusplus

@@ -9,6 +9,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define TAMF_DEV __device__ __forceinline__
 
+// Kernel-benchmark ablations (no loads / no MFMAs / no epilogue / ..., tools/kbench.py) deliberately produce wrong results: they
+// exist only in -DTAMF_BENCH builds (tools/ab_build.sh with TAMF_HIPCC_FLAGS=-DTAMF_BENCH); the product library compiles them
+// out, so no tuning word can switch arithmetic off.
+#ifdef TAMF_BENCH
+#define TAMF_ABL(x) (x)
+#else
+#define TAMF_ABL(x) 0
+#endif
+
 // -DTAMF_TIMELINE: debug build whose GEMM and attention kernels stamp per-workgroup phase times (100 MHz wall clock)
 // into device buffers read back by tamf_debug_timeline (tools/gemm_timeline.py, tools/attn_timeline.py)
 #ifdef TAMF_TIMELINE
@@ -122,6 +131,18 @@ TAMF_DEV int swz_chunk(int row) {
   } else {
     return row & 15;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sticky status word of this device (one per process and device; read and cleared by tamf_get_status_flags).
+//   bit 0 (TAMF_STATUS_F16_RANGE): a value beyond the fp16 range (|v| > 65504, +-inf included; NaN is not counted) was
+//   stored as a split-fp16 operand - its hi part is then inf, its lo part NaN, and the products it enters differ from the
+//   reference's fp32 ones.  Raised where activations are split (OpF16X3::store / store1); weights are checked on the host
+//   (upload_operand).  Attention probabilities (<= 2^8 with the deferred rescale) are split without the check.
+// ---------------------------------------------------------------------------------------------
+__device__ unsigned g_tamf_status;
+TAMF_DEV void f16_range_flag(float absmax) {
+  if (absmax > 65504.0f) atomicOr(&g_tamf_status, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,14 +301,20 @@ struct OpF16X3 {
   template <int N>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t wh[N / 2], wl[N / 2];
+    float am = 0.f;  // max |v| of the run (v_max3_f32 with |.| modifiers: one instruction per pair; NaN operands drop out)
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
+    for (int i = 0; i < N / 2; ++i) {
+      split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
+      am = fmaxf(fmaxf(am, fabsf(v[2 * i])), fabsf(v[2 * i + 1]));
+    }
+    f16_range_flag(am);
     char* p = (char*)base + byte_off(idx);
     store_bf16_vec<N>(p, wh);
     store_bf16_vec<N>(p + 64, wl);
   }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
+    f16_range_flag(fabsf(v));
     char* p = (char*)base + byte_off(idx);
     const _Float16 hi = (_Float16)v;
     *(_Float16*)p = hi;

@@ -701,7 +701,7 @@ TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, co
   const int w_frag = A_BYTES + (wn0 + lr) * BKB;
 
   const int krs = ga.krot & 0xFF;
-  const bool abl_noload = (ga.krot & 0x1000) != 0, abl_nocomp = (ga.krot & 0x2000) != 0;
+  const bool abl_noload = (TAMF_ABL(ga.krot) & 0x1000) != 0, abl_nocomp = (TAMF_ABL(ga.krot) & 0x2000) != 0;
   const int rot = krs ? (int)(((unsigned)lb * (unsigned)krs) % (unsigned)KT) : 0;
   TAMF_ISSUE_ALL(rot, 0)
   __syncthreads();

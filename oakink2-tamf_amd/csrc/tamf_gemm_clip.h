@@ -74,7 +74,7 @@ struct ClipGemmArgs {
   int n_clips, Sp;  // A has n_clips * Sp rows; a tile covers rows [b*Sp, b*Sp + Sp)
   int N, K;
   int n_tiles;      // n_clips * (N / BN)
-  int abl;          // kernel-benchmark ablations (tools/kbench.py): 1 = no loads after the first K tiles, 2 = no MFMAs, 4 = no epilogue,
+  int abl;          // kernel-benchmark ablations (-DTAMF_BENCH builds only, TAMF_ABL) (tools/kbench.py): 1 = no loads after the first K tiles, 2 = no MFMAs, 4 = no epilogue,
                     // 8 = no activation, 16 = every row tile is stored into the rows of the first one (no new lines to write back)
 };
 
@@ -459,16 +459,16 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     int t = clip_tile_of(ga.n_tiles, 0);
     bool pre = false;  // this interval's requests went out ahead of the previous tile's epilogue
     for (int j = 0; j < J; ++j) {
-      const bool ld = is.live && !(ga.abl & 1) && !pre, batch = ld || pre;
+      const bool ld = is.live && !(TAMF_ABL(ga.abl) & 1) && !pre, batch = ld || pre;
 #ifdef TAMF_TIMELINE
       const bool dbg_on = wave == 0 && j >= 4 && j < 12 && blockIdx.x < 512;
       const int it_dbg = j, lane_dbg = lane, mh_dbg = 0;
       TAMF_CLIP_TS(0)
-      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(TAMF_ABL(ga.abl) & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
                               c0, c1, acc, dbg_on, it_dbg, lane_dbg);
       TAMF_CLIP_TS(2)
 #else
-      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(ga.abl & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
+      clip_ktile_x<Op, C, NI, TR>(smem + sc * C::STAGE, smem + sn * C::STAGE, ld, !(TAMF_ABL(ga.abl) & 2), ga, is.s, nq, prow, is.kti, a_frag, w_frag,
                               c0, c1, acc);
 #endif
       if (is.live && !pre) is.advance(ga, KT, ntn, nq, prow, pch);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
                             : C::MSUBX * C::NCHUNK * Epi::CHUNK_STORES;
       constexpr int PH = C::PIECES_HI;
       static_assert(PH + SX < 64, "vmcnt range");
-      const bool behind = pre && !(ga.abl & 4);  // the stores are there
+      const bool behind = pre && !(TAMF_ABL(ga.abl) & 4);  // the stores are there
       pre = false;
       if (LA == 2 && batch) {
         if (behind) {
@@ -508,20 +508,20 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         } else {
 #pragma unroll
           for (int c = 0; c < C::NCHUNK; ++c) {
-            if (ga.abl & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
             else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
           }
         }
-        if (is.live && !(ga.abl & 1)) {
+        if (is.live && !(TAMF_ABL(ga.abl) & 1)) {
           clip_issue<Op, C>(ga, is.s, nq, prow, is.kti, smem + sn * C::STAGE);
           is.advance(ga, KT, ntn, nq, prow, pch);
           pre = true;
         }
         if constexpr (TR) {
-          if (!(ga.abl & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
         } else {
           clip_settle(bi);
-          if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, ga.abl, slot);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBX; ++mi)
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       const int it_dbg = j, lane_dbg = lane, mh_dbg = 1;
 #endif
       TAMF_CLIP_TS(0)
-      if (!(ga.abl & 2)) clip_mma_y<Op, C, NI, TR>(ywf, yaf, acc);  // K tile j - 1
+      if (!(TAMF_ABL(ga.abl) & 2)) clip_mma_y<Op, C, NI, TR>(ywf, yaf, acc);  // K tile j - 1
 #ifdef TAMF_TIMELINE
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
 #endif
@@ -565,16 +565,16 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           float bb[NI];
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) bb[ni] = epi.bias[n0 + wn0 + lr + 16 * ni];
-          if (!(ga.abl & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
         } else {
           float bi[C::NCHUNK][C::CHUNK];
 #pragma unroll
           for (int c = 0; c < C::NCHUNK; ++c) {
-            if (ga.abl & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
             else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
           }
           clip_settle(bi);
-          if (!(ga.abl & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, ga.abl, slot);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBY; ++mi)

@@ -107,6 +107,8 @@ struct tamf_ctx {
   std::vector<double> prof_flops;
 };
 
+static std::vector<tamf_ctx*> g_live_ctx;  // contexts of this process (tamf_set_gemm_tuning retires their captured graphs)
+
 static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   else g_noctx_err = msg;
@@ -159,9 +161,17 @@ static inline float h_bf2f(uint16_t h) {
 
 // upload host fp32 [N][K] as an operand matrix [N][ldk] in precision `prec` (cols >= K zero; ldk % 32 == 0).
 // bf16x3 rows are 128-byte groups of 32 elements: [hi: 32 bf16 | lo: 32 bf16] (tamf_device.h "Operand traits").
-static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out) {
+static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what) {
   const size_t n = (size_t)N * ldk;
   if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
+  if (prec == TAMF_PREC_F16X3) {
+    // range guard of the split-fp16 format (weights; activations are checked on the device, tamf_device.h g_tamf_status)
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::fmax(mx, std::fabs(w[i]));  // (fmax drops NaN)
+    if (mx > 65504.0f)
+      return fail(ctx, TAMF_ERR_RANGE, std::string("f16x3: weight ") + what + " has max |w| = " + std::to_string(mx) +
+                                           " > 65504 and cannot be stored as split-fp16 operands; use bf16x3 or f32");
+  }
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
     for (int r = 0; r < N; ++r) memcpy(&h[(size_t)r * ldk], &w[(size_t)r * K], (size_t)K * 4);
@@ -512,12 +522,14 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (rc) return bail(rc);
   if (hipEventCreateWithFlags(&ctx->graph_done, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, "hipEventCreate failed"));
+  g_live_ctx.push_back(ctx);
   *out = ctx;
   return 0;
 }
 
 extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (!ctx) return;
+  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), ctx), g_live_ctx.end());
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->graph_done) (void)hipEventDestroy(ctx->graph_done);
@@ -609,10 +621,10 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   for (int l = 0; l < ctx->L; ++l) {
     const std::string p = "seqTransEncoder.layers." + std::to_string(l);
     LayerW& w = ctx->layers[l];
-    TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win));
-    TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout));
-    TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1));
-    TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2));
+    TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win, (p + ".self_attn.in_proj_weight").c_str()));
+    TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout, (p + ".self_attn.out_proj.weight").c_str()));
+    TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
+    TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2, (p + ".linear2.weight").c_str()));
     TRY(upload_f32(ctx, p + ".self_attn.in_proj_bias", &w.b_in));
     TRY(upload_f32(ctx, p + ".self_attn.out_proj.bias", &w.b_out));
     TRY(upload_f32(ctx, p + ".linear1.bias", &w.b1));
@@ -653,17 +665,17 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
       }
       cb[n] = (float)acc_b;
     }
-    TRY(upload_operand(ctx, prec, fused.data(), d, ctx->XK, ctx->XK, &ctx->Wfused));
-    TRY(upload_operand(ctx, TAMF_PREC_F32, wm1b.data(), d, d, d, &ctx->Wm1b_f32));
+    TRY(upload_operand(ctx, prec, fused.data(), d, ctx->XK, ctx->XK, &ctx->Wfused, "input_merge.0.weight x poseEmbedding.weight (fused)"));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, wm1b.data(), d, d, d, &ctx->Wm1b_f32, "input_merge.0.weight"));
     TRY(dev_upload(ctx, &ctx->cbias, cb.data(), cb.size()));
   }
-  TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2));
+  TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2, "input_merge.2.weight"));
   TRY(upload_f32(ctx, "input_merge.2.bias", &ctx->bm2));
   {
     std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f);
     memcpy(wf.data(), R("output_process.poseFinal.weight"), (size_t)F * d * 4);
     memcpy(bfp.data(), R("output_process.poseFinal.bias"), (size_t)F * 4);
-    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf));
+    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf, "output_process.poseFinal.weight"));
     TRY(dev_upload(ctx, &ctx->bf, bfp.data(), bfp.size()));
   }
   TRY(upload_f32(ctx, "sequence_pos_encoder.pe", &ctx->pe));
@@ -678,8 +690,8 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   if (ctx->has_t) {
     TRY(upload_f32(ctx, "embed_text.weight", &ctx->Wtxt));
     TRY(upload_f32(ctx, "embed_text.bias", &ctx->btxt));
-    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.0.weight"), d, d, d, &ctx->Wt1_f32));
-    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.2.weight"), d, d, d, &ctx->Wt2_f32));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.0.weight"), d, d, d, &ctx->Wt1_f32, "embed_timestep.time_embed.0.weight"));
+    TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.2.weight"), d, d, d, &ctx->Wt2_f32, "embed_timestep.time_embed.2.weight"));
     TRY(upload_f32(ctx, "embed_timestep.time_embed.0.bias", &ctx->bt1));
     TRY(upload_f32(ctx, "embed_timestep.time_embed.2.bias", &ctx->bt2));
     // timestep-embedding table: temb[t] = nan_to_num(W2 silu(W1 pe[t] + b1) + b2) + pe[0]   (exact fp32 MFMA)
@@ -869,12 +881,14 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
           HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
         const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
         EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE};
+        mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
+        mark("gemm_v", BS * 2.0 * dd * dd);
       } else {
         EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+        mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
       }
-      mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
     }
     {
       AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H};
@@ -1088,6 +1102,20 @@ extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   TAMF_WITH_OP(ctx->prec, return loop_impl<Op>(ctx, noise_dev, seed, clip_id_base, x0_out_dev, dump_dev, use_graph, st));
+  return 0;
+}
+
+extern "C" int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t clear, void* stream) {
+  if (!ctx || !flags) return fail(ctx, TAMF_ERR_INVALID, "null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+  unsigned v = 0;
+  HIPCHK(ctx, hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tamf_status), sizeof(v), 0, hipMemcpyDeviceToHost));
+  *flags = v;
+  if (clear && v) {
+    const unsigned z = 0;
+    HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_tamf_status), &z, sizeof(z), 0, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -1444,9 +1472,15 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 }
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
-  // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..23: kernel-selection overrides
-  g_sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
-  g_krot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
+  // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..30: kernel-selection overrides (g_sel).
+  // The words are process-global and a captured loop graph has the selection of its capture time baked in, so every live
+  // context's graph is retired here: the next tamf_sample_loop re-captures with the new selection (same as tamf_denoise).
+  const int sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
+  const int rot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
+  if (sel != g_sel || rot != g_krot)
+    for (tamf_ctx* c : g_live_ctx) (void)retire_graph(c);
+  g_sel = sel;
+  g_krot = rot;
   return 0;
 }
 

@@ -70,12 +70,6 @@ def load() -> ctypes.CDLL:
     global _lib
     with _lock:
         if _lib is None:
-            override = os.environ.get("TAMF_LIB_OVERRIDE")  # A/B runs of two builds on one box (tools/ab_build.sh)
-            if override:
-                import torch  # noqa: F401
-
-                _lib = ctypes.CDLL(override)
-                return _lib
             build()
             # torch ships its own libamdhip64; import it first so that the library binds to the HIP runtime
             # instance torch uses (one runtime per process: shared device memory, streams, contexts).
@@ -85,8 +79,22 @@ def load() -> ctypes.CDLL:
         return _lib
 
 
+def load_from(path: str) -> ctypes.CDLL:
+    """Bind the process to another build of the library, given explicitly by the caller, before the first load().  For the
+    measurement scripts under tools/ (two builds alternating on one box, debug builds with timeline stamps): the product
+    path never calls this and reads no environment variable."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            raise RuntimeError("libtamf_hip is already loaded in this process")
+        import torch  # noqa: F401
+
+        _lib = ctypes.CDLL(path)
+        return _lib
+
+
 EXPORTS = [
     "tamf_ctx_create", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
     "tamf_set_schedule", "tamf_set_cond", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
-    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox", "tamf_bench_gemm", "tamf_set_gemm_tuning",
+    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox", "tamf_bench_gemm", "tamf_set_gemm_tuning",
 ]

@@ -18,6 +18,14 @@ class TamfError(RuntimeError):
     pass
 
 
+class TamfRangeError(TamfError):
+    """A weight (at load) or an activation (status flag) does not fit the split-fp16 operand format of "f16x3"."""
+
+
+STATUS_F16_RANGE = 1
+DEFAULT_PRECISION = "f16x3"  # fp32-equivalent (22 significand bits, meets the 1e-5 gate), range-guarded; DESIGN.md section 2
+
+
 class _Arch(ctypes.Structure):
     _fields_ = [
         ("input_dim", c_int32),
@@ -54,6 +62,7 @@ def lib() -> ctypes.CDLL:
         L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
         L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.tamf_get_status_flags.argtypes = [c_void_p, POINTER(ctypes.c_uint32), c_int32, c_void_p]
         L.tamf_step_kernel_count.argtypes = [c_void_p]
         L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
         L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -91,7 +100,7 @@ def _stream_ptr(device: torch.device) -> int:
 def _check(rc: int, ctx=None):
     if rc != 0:
         msg = lib().tamf_last_error(ctx)
-        raise TamfError(f"libtamf_hip error {rc}: {msg.decode() if msg else '?'}")
+        raise (TamfRangeError if rc == -6 else TamfError)(f"libtamf_hip error {rc}: {msg.decode() if msg else '?'}")
 
 
 def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
@@ -112,7 +121,7 @@ def require_gpu(device=None) -> torch.device:
 class TamfContext:
     """One library context = one (model, device, precision, max batch, max frames)."""
 
-    def __init__(self, arch: Mapping[str, int], max_batch: int, max_frames: int, precision: str = "f32",
+    def __init__(self, arch: Mapping[str, int], max_batch: int, max_frames: int, precision: str = DEFAULT_PRECISION,
                  device=None, kind: str = "G"):
         self.device = require_gpu(device)
         self.precision = precision
@@ -249,6 +258,15 @@ class TamfContext:
                                           c_void_p(_stream_ptr(dev))), self._h)
         self._keep_loop = [nz, dmp]
         return (out, dmp) if dump else out
+
+    def status_flags(self, clear: bool = True) -> int:
+        """Sticky status bits of this context's device (STATUS_F16_RANGE: an activation beyond +-65504 was stored as a
+        split-fp16 operand since the last clear).  Synchronises the current stream."""
+        v = ctypes.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _check(lib().tamf_get_status_flags(self._h, ctypes.byref(v), 1 if clear else 0, c_void_p(_stream_ptr(self.device))),
+                   self._h)
+        return int(v.value)
 
     def refine(self, sample_pose_repr: torch.Tensor, h2o_dist: torch.Tensor) -> torch.Tensor:
         dev = self.device

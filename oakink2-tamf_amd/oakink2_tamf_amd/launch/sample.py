@@ -8,7 +8,10 @@ Same flags, same yml schema (`model: {input_dim, ..., activation}`, repeated --c
 overrides such as --model.latent_dim 512), same output tree
 `<cwd>/common/sample/<exp_id>/sample/<offset>/<sample_id:06d>.npy` float32 (T, 99), nothing written without
 --commit.  Differences: clips are sampled in batches (--runtime.batch_size, default 64) instead of one by one;
-workers are one process per listed GPU; the dataset toolkit (thirdparty/OakInk2, absent) is replaced by either a
+workers default to ONE process per visible GPU (the reference's default is 8 workers on devices 0-3, launch/sample.py:114-127:
+with batched sampling a second context on the same GPU only contends for it - two B <= 64 contexts on one MI355X take as long
+as one after the other, DESIGN.md section 6 - and GPUs 4-7 of an 8-GPU node would idle); --runtime.num_worker / --runtime.device_id
+still override, at most two workers per listed device; the dataset toolkit (thirdparty/OakInk2, absent) is replaced by either a
 pre-collated conditioning file (--data.cond_npz: arrays text_embedding, hand_side, shape, obj_embedding, obj_traj
 with a leading clip axis - the tensors InteractionSegmentData + interaction_segment_collate produce)
 or synthetic conditioning (--synthetic B,T).
@@ -23,7 +26,7 @@ from typing import Dict, List
 
 import numpy as np
 
-from ..hip_backend import hand_side_code
+from ..hip_backend import DEFAULT_PRECISION, hand_side_code
 from .formats import write_sample_npy
 from .upkeep import ckpt_opt, ckpt_setup, decode_file_macro
 
@@ -56,7 +59,8 @@ def parse_args(argv: List[str]):
     ap.add_argument("--exp_id", default="main")
     ap.add_argument("--commit", action="store_true", help="write outputs (dry run otherwise)")
     ap.add_argument("--synthetic", default=None, help="B,T : synthetic conditioning for B clips of T frames")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["f32", "f16x3", "bf16x3", "bf16"],
+                    help="MFMA operand format (default: the package-wide default, fp32-equivalent split fp16 with range fallback to f32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--diffusion_steps", type=int, default=1000)
     known, rest = ap.parse_known_args(argv)
@@ -76,9 +80,9 @@ def parse_args(argv: List[str]):
 def build_config(known, dotted) -> Dict:
     import yaml
 
-    # runtime defaults of the reference (launch/sample.py:114-127): 8 workers over devices 0-3; main() clamps both to the
-    # devices and clips that exist
-    cfg: Dict = {"model": dict(MODEL_DEFAULTS), "data": {}, "debug": {}, "runtime": {"num_worker": 8, "device_id": [0, 1, 2, 3], "batch_size": 64}}
+    # runtime defaults: one worker per visible device (None = decided in main(); the reference's 8 workers over devices 0-3,
+    # launch/sample.py:114-127, would put two contexts on each of four GPUs and leave the other four idle)
+    cfg: Dict = {"model": dict(MODEL_DEFAULTS), "data": {}, "debug": {}, "runtime": {"num_worker": None, "device_id": None, "batch_size": 64}}
     for path in known.cfg:
         with open(path) as f:
             _merge(cfg, yaml.safe_load(f) or {})
@@ -191,10 +195,16 @@ def main(argv=None):
     import torch
     import torch.multiprocessing as mp
 
-    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
-    device_ids = [d for d in cfg["runtime"]["device_id"] if d < max(n_dev, 1)] or [0]
+    n_dev = max(torch.cuda.device_count(), 1)  # (on this ROCm image counting devices does not initialise the GPU in this process)
+    want = cfg["runtime"].get("device_id")
+    device_ids = ([d for d in want if d < n_dev] or [0]) if want else list(range(n_dev))
     n_clips = int(cond["shape"].shape[0])
-    num_worker = max(1, min(int(cfg["runtime"].get("num_worker") or len(device_ids)), n_clips))
+    asked = cfg["runtime"].get("num_worker")
+    num_worker = int(asked) if asked else len(device_ids)
+    if num_worker > 2 * len(device_ids):
+        _logger.warning("runtime.num_worker=%d on %d device(s): clamped to two per device", num_worker, len(device_ids))
+        num_worker = 2 * len(device_ids)
+    num_worker = max(1, min(num_worker, n_clips))
 
     if num_worker == 1:
         sample_worker(0, 1, device_ids[0], cfg, cond, known.seed, known.precision, known.diffusion_steps)

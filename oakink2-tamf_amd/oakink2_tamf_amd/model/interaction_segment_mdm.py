@@ -13,6 +13,11 @@ Differences from the reference, all deliberate:
     and pass batch["text"], in which case it is encoded once per distinct batch dict;
   * step-invariant conditioning (prefix tokens 1..4, object half of input_merge.0) is computed once per batch dict;
   * eval only (dropout is identity in the reference's eval mode; autograd is not supported);
+  * arithmetic: `precision` (default "f16x3", hip_backend.DEFAULT_PRECISION - the same default in the CLIs and bench.py)
+    selects the MFMA operand format.  "f16x3" (split fp16, fp32-equivalent at the stated 1e-5 tolerance) cannot hold values
+    beyond +-65504; `range_check` says what happens when a weight or an activation leaves that range:
+    "fallback" (default) - the call is repeated in "f32" (the reference's own arithmetic) on a new library context and the
+    module stays there; "raise" - hip_backend.TamfRangeError; "off" - no check (no stream synchronisation per call);
   * train()/eval() return self (the reference's override returns None, :176-178).
 """
 from __future__ import annotations
@@ -25,6 +30,12 @@ import torch
 import torch.nn as nn
 
 _logger = logging.getLogger(__name__)
+
+
+def _default_precision() -> str:
+    from ..hip_backend import DEFAULT_PRECISION
+
+    return DEFAULT_PRECISION
 
 
 class PositionalEncoding(nn.Module):
@@ -68,9 +79,14 @@ class _HipDenoiserBase(nn.Module):
     kind = "G"
     supports_fused_loop = False
 
-    def _init_hip(self, arch: Dict[str, int], precision: str, max_batch: Optional[int], max_frames: Optional[int]):
+    def _init_hip(self, arch: Dict[str, int], precision: str, max_batch: Optional[int], max_frames: Optional[int],
+                  range_check: str = "fallback"):
+        if range_check not in ("fallback", "raise", "off"):
+            raise ValueError(f"range_check must be 'fallback', 'raise' or 'off', got {range_check!r}")
         self._arch = dict(arch)
-        self.precision = precision
+        self.precision = precision          # what the caller asked for
+        self.active_precision = precision   # what the library context runs ("f32" after a range fallback)
+        self.range_check = range_check
         self._max_batch, self._max_frames = max_batch, max_frames
         self._ctx = None
         self._ctx_dirty = True
@@ -82,6 +98,7 @@ class _HipDenoiserBase(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._ctx_dirty = True
+        self.active_precision = self.precision  # new weights: try the requested arithmetic again
         return out
 
     def _apply(self, fn, *a, **k):
@@ -102,17 +119,52 @@ class _HipDenoiserBase(nn.Module):
         dev = require_gpu(self._device())
         need_new = (self._ctx is None or self._ctx_dirty or B > self._ctx.max_batch or T > self._ctx.max_frames
                     or self._ctx.device != dev)
-        if need_new:
+        if need_new or self._ctx.precision != self.active_precision:
+            from ..hip_backend import TamfRangeError
+
             if self._ctx is not None:
                 self._ctx.close()
+                self._ctx = None
             mb = max(B, self._max_batch or 0)
             mf = max(T, self._max_frames or 0)
-            self._ctx = TamfContext(self._arch, mb, mf, precision=self.precision, device=dev, kind=self.kind)
-            self._ctx.load_state_dict(self.state_dict(), max_timesteps=self._max_timesteps)
+            while True:
+                ctx = TamfContext(self._arch, mb, mf, precision=self.active_precision, device=dev, kind=self.kind)
+                try:
+                    ctx.load_state_dict(self.state_dict(), max_timesteps=self._max_timesteps)
+                    break
+                except TamfRangeError as e:  # a weight beyond the fp16 range
+                    ctx.close()
+                    if self.range_check != "fallback" or self.active_precision == "f32":
+                        raise
+                    _logger.warning("%s - falling back to f32 arithmetic", e)
+                    self.active_precision = "f32"
+            self._ctx = ctx
+            if self._guarded():
+                ctx.status_flags(clear=True)  # bits left by an earlier context of this process on the device
             self._ctx_dirty = False
             self._cond_key = None
             self._sched_key = None
         return self._ctx
+
+    def _guarded(self) -> bool:
+        return self.active_precision == "f16x3" and self.range_check != "off"
+
+    def _range_tripped(self, ctx) -> bool:
+        """After a call in f16x3: True when an activation left the fp16 range and the call must be repeated in f32
+        (range_check="fallback"); raises for range_check="raise"."""
+        if not self._guarded():
+            return False
+        from ..hip_backend import STATUS_F16_RANGE, TamfRangeError
+
+        if not (ctx.status_flags(clear=True) & STATUS_F16_RANGE):
+            return False
+        msg = ("f16x3: an activation beyond +-65504 was stored as a split-fp16 operand; the result may differ from the "
+               "reference's fp32 arithmetic")
+        if self.range_check == "raise":
+            raise TamfRangeError(msg + " (construct the module with precision='f32' or 'bf16x3')")
+        _logger.warning("%s - repeating the call in f32 and staying there", msg)
+        self.active_precision = "f32"
+        return True
 
     @staticmethod
     def _tensor_key(t):
@@ -141,8 +193,8 @@ class InterationSegmentMDM(_HipDenoiserBase):
 
     def __init__(self, input_dim=99, obj_input_dim=9, hand_shape_dim=10, obj_embed_dim=768, latent_dim=256,
                  ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu", clip_dim=512,
-                 clip_version="ViT-B/32", precision: str = "bf16x3", load_clip: bool = False,
-                 max_batch: Optional[int] = None, max_frames: Optional[int] = None, **kargs):
+                 clip_version="ViT-B/32", precision: Optional[str] = None, load_clip: bool = False,
+                 max_batch: Optional[int] = None, max_frames: Optional[int] = None, range_check: str = "fallback", **kargs):
         super().__init__()
         if activation != "gelu":
             raise NotImplementedError("the HIP FFN kernel fuses the exact erf-GELU (activation='gelu') only")
@@ -175,7 +227,8 @@ class InterationSegmentMDM(_HipDenoiserBase):
         self.eval()
         self._init_hip(dict(input_dim=input_dim, obj_input_dim=obj_input_dim, hand_shape_dim=hand_shape_dim,
                             obj_embed_dim=obj_embed_dim, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers,
-                            num_heads=num_heads, clip_dim=clip_dim), precision, max_batch, max_frames)
+                            num_heads=num_heads, clip_dim=clip_dim), precision or _default_precision(), max_batch, max_frames,
+                       range_check)
 
     def parameters_wo_clip(self):
         return [p for name, p in self.named_parameters() if not name.startswith("clip_model.")]
@@ -221,9 +274,12 @@ class InterationSegmentMDM(_HipDenoiserBase):
         """x: (B, input_dim, 1, T); timesteps: (B,) int; batch: dict with "text_embedding" (or "text"),
         "hand_side", "shape", "obj_embedding", "obj_traj"  ->  x0_hat (B, input_dim, 1, T)."""
         B, _, _, T = x.shape
-        ctx = self._context(B, T)
-        self._set_cond(ctx, batch, self._text_embedding(batch))
-        return ctx.denoise(x, timesteps)
+        while True:
+            ctx = self._context(B, T)
+            self._set_cond(ctx, batch, self._text_embedding(batch))
+            out = ctx.denoise(x, timesteps)
+            if not self._range_tripped(ctx):
+                return out
 
     @torch.no_grad()
     def fused_sample_loop(self, diffusion, shape, x_T=None, batch=None, dump_steps=None, noise_source="philox",
@@ -232,6 +288,15 @@ class InterationSegmentMDM(_HipDenoiserBase):
         B, F, _, T = shape
         N = diffusion.num_timesteps
         self._max_timesteps = max(self._max_timesteps, N)
+        draws = None
+        while True:
+            res, draws = self._fused_loop_once(diffusion, shape, x_T, batch, dump_steps, noise_source, seed, clip_id_base, draws)
+            if not self._range_tripped(self._ctx):
+                return res
+
+    def _fused_loop_once(self, diffusion, shape, x_T, batch, dump_steps, noise_source, seed, clip_id_base, draws):
+        B, F, _, T = shape
+        N = diffusion.num_timesteps
         ctx = self._context(B, T)
         # keyed on the coefficient values themselves (a new diffusion object at a recycled id must not hit)
         skey = (N, diffusion.posterior_mean_coef1.tobytes(), diffusion.posterior_mean_coef2.tobytes(),
@@ -242,8 +307,8 @@ class InterationSegmentMDM(_HipDenoiserBase):
             self._sched_key = skey
         self._set_cond(ctx, batch, self._text_embedding(batch))
         dev = ctx.device
-        noise = None
-        if noise_source in ("torch", "torch_cpu") or x_T is not None:
+        noise = draws  # (a repeat after a range fallback reuses the first attempt's draws: the torch generators have moved on)
+        if noise is None and (noise_source in ("torch", "torch_cpu") or x_T is not None):
             gen_dev = torch.device("cpu") if noise_source == "torch_cpu" else dev
             n_bytes = (N + 1) * B * F * T * 4
             if n_bytes > 8 << 30:
@@ -261,5 +326,5 @@ class InterationSegmentMDM(_HipDenoiserBase):
         res = ctx.sample_loop(noise=noise, seed=seed, clip_id_base=clip_id_base, dump=dump_steps is not None)
         if dump_steps is not None:
             out, dump = res
-            return [dump[i].clone() for i in range(N) if i in dump_steps]
-        return res
+            return [dump[i].clone() for i in range(N) if i in dump_steps], noise
+        return res, noise

@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .interaction_segment_mdm import HandsideProcess, PositionalEncoding, _HipDenoiserBase, _Linear
+from .interaction_segment_mdm import HandsideProcess, PositionalEncoding, _default_precision, _HipDenoiserBase, _Linear
 
 
 class SegmentRefineModel(_HipDenoiserBase):
@@ -26,8 +26,8 @@ class SegmentRefineModel(_HipDenoiserBase):
 
     def __init__(self, mano_path=None, input_dim=99, obj_input_dim=9, hand_shape_dim=10, obj_embed_dim=768,
                  latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu", use_pc=False,
-                 h2o_dim=778, precision: str = "bf16x3", max_batch=None, max_frames=None, mano_layer_rh=None,
-                 mano_layer_lh=None):
+                 h2o_dim=778, precision=None, max_batch=None, max_frames=None, mano_layer_rh=None,
+                 mano_layer_lh=None, range_check: str = "fallback"):
         super().__init__()
         if activation != "gelu":
             raise NotImplementedError("the HIP FFN kernel fuses the exact erf-GELU (activation='gelu') only")
@@ -54,7 +54,8 @@ class SegmentRefineModel(_HipDenoiserBase):
         self.eval()
         self._init_hip(dict(input_dim=input_dim, obj_input_dim=obj_input_dim, hand_shape_dim=hand_shape_dim,
                             obj_embed_dim=obj_embed_dim, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers,
-                            num_heads=num_heads, h2o_dim=h2o_dim), precision, max_batch, max_frames)
+                            num_heads=num_heads, h2o_dim=h2o_dim), precision or _default_precision(), max_batch, max_frames,
+                       range_check)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         # checkpoints of the reference also carry the manotorch buffers (mano_layer_rh.*, mano_layer_lh.*)
@@ -135,9 +136,12 @@ class SegmentRefineModel(_HipDenoiserBase):
             raise KeyError("batch['h2o_dist'] (B, T, 778) must be supplied, or the module built with mano_layer_rh / mano_layer_lh: "
                            "MANO FK is outside this package (SURVEY.md section 8f, row 1)")
         B, T, _ = x_in.shape
-        ctx = self._context(B, T)
-        self._set_cond(ctx, batch, None)
-        out = ctx.refine(x_in, h2o)
+        while True:  # (repeated once in f32 when an activation left the fp16 range of the default f16x3 mode)
+            ctx = self._context(B, T)
+            self._set_cond(ctx, batch, None)
+            out = ctx.refine(x_in, h2o)
+            if not self._range_tripped(ctx):
+                break
         res["refine_pose_repr"], res["sample_h2o_dist"] = out, h2o
         if with_refined_geometry and "h2o_dist" not in batch:
             rv, rj, rn = self.batch_recover_mano_from_pose_repr(out, batch["shape"], batch["hand_side"])

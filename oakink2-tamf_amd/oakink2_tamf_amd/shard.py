@@ -22,10 +22,13 @@ def clip_id_base(rank: int, clips_per_rank: int) -> int:
     return rank * clips_per_rank
 
 
-def gather_clips(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
-    """all_gather equal-sized per-rank results along dim 0, in rank (= global clip) order."""
+def gather_clips(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None,
+                 force_collective: bool = False) -> torch.Tensor:
+    """all_gather equal-sized per-rank results along dim 0, in rank (= global clip) order.
+    force_collective: issue the collective even in a group of one rank (the GPU test that puts the RCCL call itself
+    on a device; a single rank otherwise just copies)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         if out is not None:
             out.copy_(local)
             return out

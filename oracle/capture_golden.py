@@ -422,6 +422,17 @@ def capture_siv():
     np.savez_compressed(os.path.join(OUT_DIR, "siv.npz"), **arrays)
 
 
+def capture_loop_arch_mdm_l_1000():
+    """The path the metric is quoted on: the reference's p_sample_loop (gaussian_diffusion.py:506-640) run 1000 x over
+    arch_mdm_l at T = 196 (B = 2), det-recipe noise in reference call order; final + the states after steps 0, 499, 998."""
+    capture_loop("arch_mdm_l_b2_t196_1000", O.ARCH_MDM_L, B=2, T=196, steps=1000, store_noise=False, dump_steps=[0, 499, 998, 999])
+
+
+def capture_loop_arch_mdm_1000():
+    """BASELINE.json configs[0]'s model (arch_mdm, B = 4, T = 64) over the full 1000-step schedule."""
+    capture_loop("arch_mdm_b4_t64_1000", O.ARCH_MDM, B=4, T=64, steps=1000, store_noise=False, dump_steps=[0, 499, 998, 999])
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -445,6 +456,8 @@ def main():
     capture_loop("arch_mdm_b4_t64_50", O.ARCH_MDM, B=4, T=64, steps=50, store_noise=False)
     # full-length loop on the tiny arch
     capture_loop("tiny_1000", O.ARCH_TINY, B=2, T=16, steps=1000, store_noise=False)
+    capture_loop_arch_mdm_l_1000()
+    capture_loop_arch_mdm_1000()
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()

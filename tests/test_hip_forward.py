@@ -111,7 +111,7 @@ def test_loop_config0_arch_mdm_b4_t64_50(prec):
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", PRECS)
 def test_loop_tiny_1000(prec):
     from oracle import det
     from oracle import mdm_oracle as O
@@ -128,6 +128,48 @@ def test_loop_tiny_1000(prec):
     out = ctx.sample_loop(noise=draws).cpu().numpy()
     err = np.abs(out - fix["final"]).max()
     assert err < LOOP_TOL[prec], (prec, err)
+    ctx.close()
+
+
+_DRAWS_1000 = {}
+
+
+def _draws_1000(name, shape):
+    """(1001, B, 99, 1, T) det-recipe draws of a 1000-step fixture, generated once per test session (150 MB at T = 196)"""
+    from oracle import det
+
+    if name not in _DRAWS_1000:
+        _DRAWS_1000.clear()  # one fixture's draws at a time
+        _DRAWS_1000[name] = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape) for k in range(1001)]))
+    return _DRAWS_1000[name]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name,arch_name,B,T", [("arch_mdm_b4_t64_1000", "ARCH_MDM", 4, 64), ("arch_mdm_l_b2_t196_1000", "ARCH_MDM_L", 2, 196)])
+def test_loop_1000_real_architectures(name, arch_name, B, T, prec):
+    """The path the metric is quoted on: the reference's p_sample_loop (gaussian_diffusion.py:506-640) run 1000 x over arch_mdm_l
+    at T = 196 (and over arch_mdm), reference outputs after steps 0, 499, 998 and the final sample, in every arithmetic mode.
+    Errors do not grow with the step count (x0-prediction: the last step returns G(x_1, t = 0) itself), so the gates are the
+    single-evaluation gates."""
+    from oracle import mdm_oracle as O
+
+    fix = load_golden(f"loop_{name}.npz")
+    arch = getattr(O, arch_name)
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (B, 99, 1, T)
+    ctx = _make_ctx(arch, sd, B, T, prec, n_steps=1000)
+    _set_cond(ctx, cond)
+    out, dump = ctx.sample_loop(noise=_draws_1000(name, shape), dump=True)
+    errs = {}
+    for s_ in fix["dump_steps"]:
+        errs[int(s_)] = float(np.abs(dump[int(s_)].cpu().numpy() - fix[f"dump/{int(s_)}"]).max())
+    errs["final"] = float(np.abs(out.cpu().numpy() - fix["final"]).max())
+    print(f"1000-step loop {name}[{prec}]: max|err| vs reference {errs}")
+    assert torch.isfinite(out).all()
+    assert max(errs.values()) < LOOP_TOL[prec], (name, prec, errs)
+    if prec == "f16x3":
+        assert ctx.status_flags() == 0  # nothing left the fp16 range in 1000 steps
     ctx.close()
 
 

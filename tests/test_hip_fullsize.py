@@ -92,7 +92,7 @@ def test_loop5_b64_t196_vs_oracle(full, prec):
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", [p for p in PRECS if p != "bf16"])
+@pytest.mark.parametrize("prec", PRECS)
 def test_clip_in_b64_equals_clip_alone(full, prec):
     """Sharding invariance at the bench shape: a clip's Philox-noise sample does not depend on the batch around it."""
     N = 3

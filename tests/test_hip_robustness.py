@@ -111,7 +111,7 @@ def test_ddpm_step_entry_point():
     ctx.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3", "bf16"])
 def test_clip_sample_independent_of_batch_size_and_position(prec):
     """Sharding invariance: with Philox noise keyed by the global clip id, a clip's sample is
     bit-identical whether it is sampled alone, as part of a larger batch, or at another batch position - no kernel's
@@ -174,3 +174,112 @@ def test_graph_is_captured_once_per_shape_and_spans_several_steps():
         out2 = ctx.sample_loop(noise=draws.flip(1).contiguous()).cpu()
         assert ctx.loop_stats()[0] == 1 and not torch.equal(out, out2)
         ctx.close()
+
+
+# ---- range guard of the split-fp16 mode (include/tamf_hip.h: tamf_get_status_flags, TAMF_ERR_RANGE) --------------------------
+def _blow_up_ffn_hidden(sd, scale):
+    """linear1 of layer 0 scaled so that the FFN hidden activations H = GELU(W1 x + b1) leave the fp16 range (x is a
+    LayerNorm output, O(1)): finite in fp32, not representable as split fp16."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["seqTransEncoder.layers.0.linear1.weight"] *= scale
+    return sd
+
+
+def test_f16x3_activation_overflow_raises_the_status_flag():
+    from oakink2_tamf_amd.hip_backend import STATUS_F16_RANGE
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="rob/w")
+    cond = _cond(2, 16, "range")
+    x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([10, 700])
+    # in range: no flag, in any call
+    ctx = _ctx(arch, sd, 2, 16, "f16x3")
+    _set_cond(ctx, cond)
+    ctx.status_flags()  # clear what earlier tests may have left on the device
+    ctx.denoise(x, t)
+    ctx.sample_loop(noise=None, seed=1)
+    assert ctx.status_flags() == 0
+    ctx.close()
+    # W1 large but representable (max |w| ~ 3e4 < 65504): the weights load, the hidden activations overflow -> flag
+    w1 = sd["seqTransEncoder.layers.0.linear1.weight"]
+    scale = 3.0e4 / float(w1.abs().max())
+    big = _blow_up_ffn_hidden(sd, scale)
+    ref = O.denoiser_forward(big, arch, x, t, cond)
+    assert torch.isfinite(ref).all()  # fp32 (the reference's arithmetic) is fine with these weights
+    ctx = _ctx(arch, big, 2, 16, "f16x3")
+    _set_cond(ctx, cond)
+    ctx.denoise(x, t)
+    assert ctx.status_flags(clear=False) & STATUS_F16_RANGE
+    assert ctx.status_flags() & STATUS_F16_RANGE  # sticky until cleared
+    assert ctx.status_flags() == 0
+    ctx.close()
+    # the same weights in f32: correct, and no flag
+    ctx = _ctx(arch, big, 2, 16, "f32")
+    _set_cond(ctx, cond)
+    out = ctx.denoise(x, t).cpu()
+    assert ctx.status_flags() == 0
+    assert float((out - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+    ctx.close()
+
+
+def test_f16x3_weight_beyond_range_is_refused_at_load():
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfRangeError
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _arch_dict
+
+    arch = O.ARCH_TINY
+    sd = {k: v.clone() for k, v in O.det_state_dict(arch, tag="rob/w").items()}
+    sd["seqTransEncoder.layers.1.linear2.weight"][3, 7] = 7.0e4
+    ctx = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3")
+    with pytest.raises(TamfRangeError, match="layers.1.linear2.weight"):
+        ctx.load_state_dict(sd)
+    ctx.close()
+    for prec in ("bf16x3", "f32"):  # the other formats have fp32's exponent range
+        ctx = TamfContext(_arch_dict(arch), 2, 16, precision=prec)
+        ctx.load_state_dict(sd)
+        ctx.close()
+
+
+@pytest.mark.parametrize("how", ["activation", "weight"])
+def test_module_falls_back_to_f32_when_the_fp16_range_is_left(how):
+    """The drop-in module's default precision is f16x3 with range_check='fallback': out-of-range weights or activations
+    make it repeat the call in f32 - bit-identical to a module built with precision='f32' - and stay there;
+    range_check='raise' raises instead."""
+    from oakink2_tamf_amd.hip_backend import TamfRangeError
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+    from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY
+    kw = dict(latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    sd = O.det_state_dict(arch, tag="rob/w")
+    if how == "activation":
+        w1 = sd["seqTransEncoder.layers.0.linear1.weight"]
+        sd = _blow_up_ffn_hidden(sd, 3.0e4 / float(w1.abs().max()))
+    else:
+        sd = {k: v.clone() for k, v in sd.items()}
+        sd["seqTransEncoder.layers.0.linear1.weight"][0, 0] = 1.0e5
+    cond = _cond(2, 16, "range")
+    batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in cond.items()}
+    x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(5)).cuda()
+    t = torch.tensor([10, 700]).cuda()
+    m = InterationSegmentMDM(**kw).cuda()
+    assert m.precision == "f16x3" and m.range_check == "fallback"
+    m.load_state_dict(sd)
+    m32 = InterationSegmentMDM(**kw, precision="f32").cuda()
+    m32.load_state_dict(sd)
+    out, ref = m(x, t, batch), m32(x, t, batch)
+    assert m.active_precision == "f32" and torch.equal(out, ref)
+    dif = create_gaussian_diffusion(diffusion_steps=6, noise_schedule="cosine")
+    m.load_state_dict(sd)  # new weights: the requested arithmetic is tried again
+    assert m.active_precision == "f16x3"
+    s1 = dif.p_sample_loop(m, (2, 99, 1, 16), clip_denoised=False, model_kwargs={"batch": batch}, seed=3)
+    s2 = dif.p_sample_loop(m32, (2, 99, 1, 16), clip_denoised=False, model_kwargs={"batch": batch}, seed=3)
+    assert m.active_precision == "f32" and torch.equal(s1, s2)
+    mr = InterationSegmentMDM(**kw, range_check="raise").cuda()
+    mr.load_state_dict(sd)
+    with pytest.raises(TamfRangeError):
+        mr(x, t, batch)

@@ -188,7 +188,9 @@ def test_file_macro_and_process_range(tmp_path):
     assert cfg["data"]["process_range"] == ["scene_c", "scene_b", "scene_a"]
     cond = S.load_conditioning(cfg, known)
     assert cond["shape"].shape[0] == 3 and list(cond["hand_side"]) == ["rh", "rh", "rh"]  # clips 0, 2, 4 in file order
-    assert cfg["runtime"]["num_worker"] == 8 and cfg["runtime"]["device_id"] == [0, 1, 2, 3]  # the reference's defaults
+    # defaults: one worker per visible device, decided in main() (not the reference's 8 workers on devices 0-3)
+    assert cfg["runtime"]["num_worker"] is None and cfg["runtime"]["device_id"] is None
+    assert known.precision == "f16x3"  # the one package-wide default precision
 
 
 def test_ckpt_setup_log_file(tmp_path, monkeypatch):

@@ -120,6 +120,24 @@ def test_loop_tiny_1000():
     np.testing.assert_allclose(out.numpy(), fix["final"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("name,arch_name,B,T", [("arch_mdm_b4_t64_1000", "ARCH_MDM", 4, 64), ("arch_mdm_l_b2_t196_1000", "ARCH_MDM_L", 2, 196)])
+def test_loop_1000_real_architectures(name, arch_name, B, T):
+    """The full 1000-step reverse loop of the reference (gaussian_diffusion.py:506-640) on arch_mdm and on arch_mdm_l at T = 196 -
+    the path the bench metric is quoted on: the oracle reproduces the reference's states after steps 0, 499, 998 and the final
+    sample (captured by oracle/capture_golden.py:capture_loop_arch_mdm*_1000; observed <= 1.6e-6)."""
+    fix = load_golden(f"loop_{name}.npz")
+    arch = getattr(O, arch_name)
+    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (B, 99, 1, T)
+    dump = []
+    out = O.sample_loop(sd, arch, O.make_tables(1000, "cosine"), cond, shape,
+                        lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape)), dump=dump)
+    for s_ in fix["dump_steps"]:
+        np.testing.assert_allclose(dump[int(s_)].numpy(), fix[f"dump/{int(s_)}"], rtol=0, atol=1e-5, err_msg=f"step {int(s_)}")
+    np.testing.assert_allclose(out.numpy(), fix["final"], rtol=0, atol=1e-5)
+
+
 def test_final_step_is_pure_x0_prediction():
     # coef1[0] = 1, coef2[0] = 0, no noise at i = 0  (SURVEY.md A.3)
     tab = O.make_tables(50, "cosine")

@@ -70,3 +70,20 @@ def test_gather_world2_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True, True), (1, True, True)]
+
+
+def test_gather_force_collective_world1_gloo():
+    """A group of ONE rank normally short-circuits to a copy; force_collective runs the real all_gather_into_tensor (the GPU
+    suite uses this to put the RCCL call on a device with a single GPU, tests/test_hip_rccl.py)."""
+    from oakink2_tamf_amd import shard
+
+    assert not dist.is_initialized()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        x = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+        out = torch.empty_like(x)
+        got = shard.gather_clips(x, out, force_collective=True)
+        assert got is out and torch.equal(out, x)
+        assert torch.equal(shard.gather_clips(x, force_collective=True), x)
+    finally:
+        dist.destroy_process_group()

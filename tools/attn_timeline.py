@@ -2,6 +2,7 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
+sys.path.insert(0, os.path.join(ROOT, "tools")); import _ablib  # noqa: E702,F401  (TAMF_LIB_OVERRIDE: A/B builds)
 import numpy as np, torch
 from oakink2_tamf_amd import hip_backend as hb
 prec = sys.argv[1]

@@ -4,6 +4,8 @@
 #   hbm_traffic_<dtype>.json       FETCH_SIZE / WRITE_SIZE (separate --pmc passes), per kernel class and launch
 #   step_profile_<dtype>.json      bench.py's in-run HIP-event profile of one step
 #   bench_default.log              the default bench line
+# Pass the commit the tree was built from as TAMF_COMMIT=<sha> (the GPU box has no .git): it is stamped into hbm_traffic_*.json,
+# which bench.py reports as roofline.traffic_source.
 export TMPDIR=/tmp
 out=gpurun_out/prof; rm -rf $out; mkdir -p $out
 for dt in ${1:-f16x3 f32 bf16 bf16x3}; do
@@ -24,7 +26,7 @@ PY
     timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${dt}_$ctr -o r -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also "" --dtype $dt > $out/pmc_$dt.log 2>&1
   done
   python3 - $out $dt <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out, dt = sys.argv[1:3]
 CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_kernel", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
            ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
@@ -52,7 +54,7 @@ for k in sorted(set(fe) | set(wr)):
     kern[name] = {"fetch_bytes_corrected": f_b, "write_bytes": w_b, "traffic_bytes_per_launch": f_b + w_b}
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also '' --dtype " + dt,
            "correction": "counters are reported in KiB; gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; counters are fabric-side (Infinity Cache hits included); median over the launches of a kernel class",
-           "dtype": dt, "B": 64, "T": 196, "kernels": kern}, open(f"{out}/hbm_traffic_{dt}.json", "w"), indent=1)
+           "dtype": dt, "B": 64, "T": 196, "commit": os.environ.get("TAMF_COMMIT", "unstamped"), "kernels": kern}, open(f"{out}/hbm_traffic_{dt}.json", "w"), indent=1)
 PY
   rm -rf $out/pmc_${dt}_FETCH_SIZE $out/pmc_${dt}_WRITE_SIZE
   python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also "" --dtype $dt --profile-out $out/step_profile_$dt.json > $out/step_$dt.log 2>&1

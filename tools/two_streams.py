@@ -6,6 +6,7 @@ the lock-step single batch is not beaten."""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
+sys.path.insert(0, os.path.join(ROOT, "tools")); import _ablib  # noqa: E702,F401  (TAMF_LIB_OVERRIDE: A/B builds)
 import torch
 from oakink2_tamf_amd.hip_backend import TamfContext
 from oracle import mdm_oracle as O
