@@ -251,6 +251,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnArgs<Op> aa) {
   if (q >= Sp) return;
   const float inv = 1.0f / l_run;
   // lane (g, lr): query q, e = 16 nt + 4g + reg -> 4 consecutive elements per tile
+  // (outputs are convex combinations of V rows, which the QKV epilogue range-checks: plain stores)
 #pragma unroll
   for (int nt = 0; nt < NT16; ++nt) {
     float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};

@@ -137,7 +137,7 @@ TAMF_DEV int swz_chunk(int row) {
 // Sticky status word of this device (one per process and device; read and cleared by tamf_get_status_flags).
 //   bit 0 (TAMF_STATUS_F16_RANGE): a value beyond the fp16 range (|v| > 65504, +-inf included; NaN is not counted) was
 //   stored as a split-fp16 operand - its hi part is then inf, its lo part NaN, and the products it enters differ from the
-//   reference's fp32 ones.  Raised where activations are split (OpF16X3::store / store1); weights are checked on the host
+//   reference's fp32 ones.  Raised by the kernels that split activations (Op::store_rc + Op::range_flag); weights are checked on the host
 //   (upload_operand).  Attention probabilities (<= 2^8 with the deferred rescale) are split without the check.
 // ---------------------------------------------------------------------------------------------
 __device__ unsigned g_tamf_status;
@@ -187,6 +187,9 @@ struct OpF32 {
       *(float2*)p = make_float2(v[0], v[1]);
     }
   }
+  template <int N>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  static TAMF_DEV void range_flag(float) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = v; }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return base[idx]; }
 };
@@ -224,6 +227,9 @@ struct OpBF16 {
     for (int i = 0; i < N / 2; ++i) w[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
     store_bf16_vec<N>((char*)base + idx * 2, w);
   }
+  template <int N>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  static TAMF_DEV void range_flag(float) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = (uint16_t)f2bf(v); }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return bf2f(base[idx]); }
 };
@@ -260,6 +266,9 @@ struct OpBF16X3 {
     store_bf16_vec<N>(p, wh);
     store_bf16_vec<N>(p + 64, wl);
   }
+  template <int N>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  static TAMF_DEV void range_flag(float) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
     char* p = (char*)base + byte_off(idx);
@@ -301,20 +310,24 @@ struct OpF16X3 {
   template <int N>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t wh[N / 2], wl[N / 2];
-    float am = 0.f;  // max |v| of the run (v_max3_f32 with |.| modifiers: one instruction per pair; NaN operands drop out)
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-      split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
-      am = fmaxf(fmaxf(am, fabsf(v[2 * i])), fabsf(v[2 * i + 1]));
-    }
-    f16_range_flag(am);
+    for (int i = 0; i < N / 2; ++i) split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
     char* p = (char*)base + byte_off(idx);
     store_bf16_vec<N>(p, wh);
     store_bf16_vec<N>(p + 64, wl);
   }
+  // range-checked store: folds max |v| of the run into the caller's accumulator `am` (v_max3_f32 with |.| modifiers: one
+  // instruction per pair, NaN operands drop out); the caller raises the status bit ONCE, after its loops (range_flag) - a
+  // compare + branch + atomic inside a row loop keeps the compiler from pipelining it (QKV epilogue: 66 -> 82 us)
+  template <int N>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float& am) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) am = fmaxf(fmaxf(am, fabsf(v[2 * i])), fabsf(v[2 * i + 1]));
+    store<N>(base, idx, v);
+  }
+  static TAMF_DEV void range_flag(float am) { f16_range_flag(am); }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
-    f16_range_flag(fabsf(v));
     char* p = (char*)base + byte_off(idx);
     const _Float16 hi = (_Float16)v;
     *(_Float16*)p = hi;

@@ -115,19 +115,23 @@ struct EpiBiasAct {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;
+    float am = 0.f;
     for (int row = tid / VPR; row < BM; row += RSTEP) {
       const int gr = m0 + row;
       if (gr >= M) break;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
-      finish_act<8>(act, gr, gn, v, cc.bi);
+      finish_act<8>(act, gr, gn, v, cc.bi, am);
     }
+    OutOp::range_flag(am);
   }
+  static TAMF_DEV void range_flag(float am) { OutOp::range_flag(am); }
   // bias, row term, activation and operand store of N (4 or 8) consecutive columns gn .. of row gr: shared by the LDS-walking
   // form above and the register form of tamf_gemm_clip.h, so both produce the same bits.  `a` = this->act (the register form
-  // passes it as a literal per branch, so that its unrolled row tiles carry one activation)
+  // passes it as a literal per branch, so that its unrolled row tiles carry one activation).  `am`: range accumulator of the
+  // caller (Op::store_rc), flagged once after its loops
   template <int N>
-  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], float& am) const {
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] += bi[j];
     if (rowadd) {
@@ -153,7 +157,7 @@ struct EpiBiasAct {
         for (int j = 0; j < N; ++j) v[j] = gelu_erf_fast(v[j]);
       }
     }
-    OutOp::template store<N>(out, (long)gr * ldo + gn, v);
+    OutOp::template store_rc<N>(out, (long)gr * ldo + gn, v, am);
   }
   // register form: a lane stores 16 bytes per instruction - 4 columns of a 4-byte output, 8 of a 16-bit plane
   static constexpr int LANE_CHUNK = OutOp::PREC == 0 ? 4 : 8;
@@ -181,12 +185,13 @@ struct EpiQK {
   static constexpr bool TRANSPOSED = false;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;
   template <int N>
-  TAMF_DEV void finish_act(int, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+  TAMF_DEV void finish_act(int, int gr, int gn, float (&v)[N], const float (&bi)[N], float& am) const {
     const float sc = (gn < d) ? qscale : 1.0f;
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] = (v[j] + bi[j]) * sc;
-    Op::template store<N>(qk, (long)gr * (2 * d) + gn, v);
+    Op::template store_rc<N>(qk, (long)gr * (2 * d) + gn, v, am);
   }
+  static TAMF_DEV void range_flag(float am) { Op::range_flag(am); }
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const { g_loadn<N>(bias + gn, bi); }
 };
@@ -202,10 +207,11 @@ struct EpiVt {
   // feature eg (column of the V block) of clip b: N stored key positions from pos0 (N = 8: one 16-byte piece per 16-bit plane,
   // the keys 4g .. 4g+3 of two consecutive 16-key groups, vt_key_pos; N = 4: four consecutive keys, f32)
   template <int N>
-  TAMF_DEV void store_keys(int b, int eg, int pos0, const float (&v)[N]) const {
+  TAMF_DEV void store_keys(int b, int eg, int pos0, const float (&v)[N], float& am) const {
     const int h = eg / hd, e = eg % hd;
-    Op::template store<N>(vt, ((long)(b * H + h) * hd + e) * Skp + pos0, v);
+    Op::template store_rc<N>(vt, ((long)(b * H + h) * hd + e) * Skp + pos0, v, am);
   }
+  static TAMF_DEV void range_flag(float am) { Op::range_flag(am); }
 };
 
 // in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed
@@ -226,6 +232,7 @@ struct EpiQKV {
       const int col = (tid % VPR) * 8, gn = n0 + col;
       float b[8];
       g_load8(bias + gn, b);
+      float am = 0.f;
       for (int row = tid / VPR; row < BM; row += RSTEP) {
         const int gr = m0 + row;
         if (gr >= M) break;
@@ -233,8 +240,9 @@ struct EpiQKV {
         ct_load8(Ct, LDC, row, col, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
-        Op::template store<8>(qk, (long)gr * (2 * d) + gn, v);
+        Op::template store_rc<8>(qk, (long)gr * (2 * d) + gn, v, am);
       }
+      Op::range_flag(am);
     } else if constexpr (Op::PREC == 0) {
       // f32: V^T rows keep the natural key order; one thread = 8 consecutive keys of one feature
       for (int it = tid; it < (BM / 8) * BN; it += NT) {
@@ -260,6 +268,7 @@ struct EpiQKV {
       constexpr int NB32 = BM / 32, WITER = NB32 * (BN / 8);  // wave-iterations of the tile
       const int lane = tid & 63, wv = tid >> 6;
       const int e_lo = lane >> 3, u_lo = (lane >> 2) & 1, gq = lane & 3;
+      float am = 0.f;
       for (int wi = wv; wi < WITER; wi += NT / 64) {
         const int col = (wi / NB32) * 8 + e_lo, row0 = (wi % NB32) * 32 + u_lo * 16 + gq * 4;
         const int gr0 = m0 + row0;
@@ -271,8 +280,9 @@ struct EpiQKV {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;
-        Op::template store<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v);
+        Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
       }
+      Op::range_flag(am);
     }
   }
 };
@@ -295,6 +305,7 @@ struct EpiSeqRows {
     const int col = (tid % VPR) * 8, gn = n0 + col;
     float bi[8];
     g_load8(bias + gn, bi);
+    float am = 0.f;
     for (int row = tid / VPR; row < BM; row += RSTEP) {
       const int gr = m0 + row;
       if (gr >= M) break;
@@ -306,8 +317,9 @@ struct EpiSeqRows {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
       if (xout) g_store8(xout + orow * d + gn, v);
-      if (xop) Op::template store<8>(xop, orow * d + gn, v);
+      if (xop) Op::template store_rc<8>(xop, orow * d + gn, v, am);
     }
+    Op::range_flag(am);
   }
 };
 
@@ -356,6 +368,7 @@ struct EpiLN {
         for (int j = 0; j < VPL; ++j) rs[i][j] = rp[j];
       }
     }
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int row = wave + i * NW;
@@ -402,8 +415,9 @@ struct EpiLN {
       } else {
         *(float2*)op = make_float2(v[0], v[1]);
       }
-      Op::template store<VPL>(xop, (long)gr * BN + c0, v);
+      Op::template store_rc<VPL>(xop, (long)gr * BN + c0, v, am);
     }
+    Op::range_flag(am);
   }
 };
 
@@ -432,6 +446,7 @@ struct EpiHead {
     const int col = (tid % VPR) * 8, gn = n0 + col;
     float bi[8];
     g_load8(bias + gn, bi);
+    float am = 0.f;
     for (int row = tid / VPR; row < BM; row += RSTEP) {
       const int gr = m0 + row;
       if (gr >= M) break;
@@ -497,9 +512,10 @@ struct EpiHead {
           }
         }
         g_store8(xs + srow + gn, xn);
-        Op::template store<8>(xs_op, srow + gn, xn);
+        Op::template store_rc<8>(xs_op, srow + gn, xn, am);
       }
     }
+    Op::range_flag(am);
   }
 };
 
@@ -539,12 +555,14 @@ struct EpiStoreF32 {
       const int gr = m0 + row;
       if (gr >= M) break;
       float v[8];
+      float am = 0.f;
       ct_load8(Ct, LDC, row, col, v);
-      finish_act<8>(act, gr, gn, v, cc.bi);
+      finish_act<8>(act, gr, gn, v, cc.bi, am);
     }
   }
+  static TAMF_DEV void range_flag(float) {}  // (fp32 output: nothing to check)
   template <int N>
-  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N]) const {
+  TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], float&) const {
 #pragma unroll
     for (int j = 0; j < N; ++j) v[j] += bi[j];
     if (a == ACT_SILU) {
@@ -743,6 +761,10 @@ TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, co
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) Op::mma(acc[mi][ni], wf[ni], af[mi]);  // D rows = n (4g+reg), cols = m (lr)
       }
+      // the MFMAs are pure register operations, so the scheduler is free to sink them below the barrier's s_waitcnt vmcnt(0) -
+      // which then waits for the next tile's LDS-DMA BEFORE the math that was meant to cover it (hipcc 7.2 does exactly that once
+      // the block above is straight-line code: QKV 66 -> 80 us).  Nothing crosses this point.
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     tsink ^= tv;  // consumed after the barrier's vmcnt(0): keeps the touch load alive without an extra wait

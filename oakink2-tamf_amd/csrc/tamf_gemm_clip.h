@@ -245,7 +245,7 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
 // gn + 4 CH c .. + CH (column tile c for CH = 4, column tiles 2c and 2c + 1 for CH = 8)
 template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                                  const float (&bi)[C::NCHUNK][C::CHUNK]) {
+                                  const float (&bi)[C::NCHUNK][C::CHUNK], float& am) {
   constexpr int CH = C::CHUNK;
 #pragma unroll
   for (int mi = 0; mi < MS; ++mi) {
@@ -256,7 +256,7 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
         float v[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) v[j] = acc[mi][c * (CH / 4) + j / 4][j % 4];
-        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c]);
+        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c], am);
       }
     }
   }
@@ -269,7 +269,7 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
 template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
                                      const float (&bi)[C::NCHUNK][C::CHUNK], char* slot /* wave scratch + 16 * lane */,
-                                     bool one_row = false) {
+                                     float& am, bool one_row = false) {
   constexpr int CH = C::CHUNK;
 #pragma clang loop unroll(disable)
   for (int mi = 0; mi < MS; ++mi) {
@@ -289,7 +289,7 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
         float v[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) v[j] = a[c * (CH / 4) + j / 4][j % 4];
-        epi.template finish_act<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c]);
+        epi.template finish_act<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c], am);
       }
     }
   }
@@ -297,18 +297,20 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
 template <class C, int NI, int MS, class Epi>
 TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
                               const float (&bi)[C::NCHUNK][C::CHUNK], int abl, char* slot) {
+  float am = 0.f;  // range accumulator of the operand stores (Op::store_rc), flagged once per tile and wave
   if (abl & 24) {  // (benchmark ablations: 8 = no activation, 16 = every row of the tile is stored into the clip's first row)
-    if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, (abl & 16) != 0);
-    else clip_store_rows_rolled<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, slot, (abl & 16) != 0);
+    if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, am, (abl & 16) != 0);
+    else clip_store_rows_rolled<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, slot, am, (abl & 16) != 0);
     return;
   }
   if (epi.act == ACT_GELU) {
-    clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot);
+    clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, am);
   } else if (epi.act == ACT_SILU) {
-    clip_store_rows_rolled<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi, slot);
+    clip_store_rows_rolled<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi, slot, am);
   } else {
-    clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi);
+    clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, am);
   }
+  Epi::range_flag(am);
 }
 
 // Register epilogue of the transposed form (EpiVt): lane (lr, g) holds, per row tile and column tile ni, feature
@@ -321,6 +323,7 @@ template <class Op, class C, int NI, int FIRST, int MS, class Epi>
 TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int g, int Sp, int b, int eg0 /* feature of ni = 0 */,
                             const float (&bb)[NI]) {
   static_assert(FIRST % 2 == 0, "row-tile pairs must not straddle the X / Y split");
+  float am = 0.f;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bb[ni]));  // (one wait, ahead of the stores)
   if constexpr (Op::PREC == 0) {
@@ -332,7 +335,7 @@ TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], in
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? acc[mi][ni][j] + bb[ni] : 0.f;
-        epi.template store_keys<4>(b, eg0 + 16 * ni, tok, v);
+        epi.template store_keys<4>(b, eg0 + 16 * ni, tok, v, am);
       }
     }
   } else {
@@ -349,10 +352,11 @@ TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], in
           if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? acc[2 * u + 1][ni][j] + bb[ni] : 0.f;
           else v[4 + j] = 0.f;
         }
-        epi.template store_keys<8>(b, eg0 + 16 * ni, (s0 >> 1) * 32 + 8 * g, v);
+        epi.template store_keys<8>(b, eg0 + 16 * ni, (s0 >> 1) * 32 + 8 * g, v, am);
       }
     }
   }
+  Epi::range_flag(am);
 }
 
 // a (free) register use that makes the compiler wait for the column constants HERE, once, and not at their first use inside

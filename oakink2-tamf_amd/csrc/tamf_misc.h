@@ -34,7 +34,9 @@ __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__
   float* p = xs + (long)bt * XK + cg * 8;
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  Op::template store<8>(xs_op, (long)bt * XK + cg * 8, v);
+  float am = 0.f;
+  Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);
+  Op::range_flag(am);
 }
 
 // frame-major state -> (B, F, 1, T)
@@ -63,7 +65,9 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
     else if (c < F + Hd) val = h2o[(long)bt * Hd + (c - F)];
     v[j] = val;
   }
-  Op::template store<8>(xs_op, (long)bt * XK + cg * 8, v);
+  float am = 0.f;
+  Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);
+  Op::range_flag(am);
 }
 
 // Rows the encoder input needs besides the frame tokens, every step: prefix row 0 = timestep-embedding table
@@ -95,7 +99,9 @@ __global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* X
   const long o = ((long)b * Sp + s) * d + cg * 8;
   *(float4*)(X + o) = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(X + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  Op::template store<8>(Xop, o, v);
+  float am = 0.f;
+  Op::template store_rc<8>(Xop, o, v, am);
+  Op::range_flag(am);
 }
 
 // y = LayerNorm(resid + c) * gamma + beta, one wave per row of D = 64 * VPL columns; writes fp32 + operand
@@ -147,7 +153,9 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
 #pragma unroll
     for (int j = 0; j < VPL; ++j) xout[(long)row * D + c0 + j] = v[j];
   }
-  Op::template store<VPL>(xop, (long)row * D + c0, v);
+  float am = 0.f;
+  Op::template store_rc<VPL>(xop, (long)row * D + c0, v, am);
+  Op::range_flag(am);
 }
 
 // current timestep of every clip; clamped to the rows of the timestep-embedding table (the host wrapper raises on an

@@ -62,7 +62,8 @@ def lib() -> ctypes.CDLL:
         L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
         L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-        L.tamf_get_status_flags.argtypes = [c_void_p, POINTER(ctypes.c_uint32), c_int32, c_void_p]
+        if hasattr(L, "tamf_get_status_flags"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
+            L.tamf_get_status_flags.argtypes = [c_void_p, POINTER(ctypes.c_uint32), c_int32, c_void_p]
         L.tamf_step_kernel_count.argtypes = [c_void_p]
         L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
         L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
