@@ -226,6 +226,11 @@ int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t 
  * K-loop rotation, L2 touch-prefetch distance, ablation flags). */
 int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                     int32_t iters, float* ms_out, void* stream);
+/* Average milliseconds of `iters` launches of the attention kernel alone on random Q | K / V^T operands resident in HBM (B clips,
+ * S tokens, H heads of hd).  tuning: tamf_set_gemm_tuning word for the call (-1 = defaults; selection bit 512 = streaming kernel);
+ * abl: ablation bits of csrc/tamf_attn.h AttnArgs::abl (honoured by -DTAMF_BENCH builds only). */
+int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t iters, int32_t abl, int32_t tuning,
+                         float* ms_out, void* stream);
 /* Override the GEMM tuning / kernel-selection bits for every subsequent launch (-1 restores the per-kernel defaults); process-global;
  * retires the captured loop graphs of all live contexts so that the next tamf_sample_loop re-captures with the new selection.
  * The ablation bits (no loads / no MFMAs / no epilogue) only exist in -DTAMF_BENCH builds of the library. */

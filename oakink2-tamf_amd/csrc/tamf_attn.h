@@ -21,6 +21,8 @@ struct AttnArgs {
   const typename Op::elem_t* vt;  // [B*H*hd][Skp]
   typename Op::elem_t* out;       // [B*Sp][d]
   int S, Sp, Skp, d, H;
+  int abl;  // kernel-benchmark ablations of attn_res_kernel (-DTAMF_BENCH builds only, TAMF_ABL; tools/attn_bench.py): 1 = no LDS-DMA,
+            // 2 = no MFMAs, 4 = no fragment reads, 8 = no exp2 / hi-lo split, 16 = no output store
 };
 
 template <class Op, int HD>
@@ -256,5 +258,294 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnArgs<Op> aa) {
   for (int nt = 0; nt < NT16; ++nt) {
     float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
     Op::template store<4>(aa.out, (row_base + q) * d + h * HD + nt * 16 + 4 * g, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Resident-K attention for the 16-bit modes and sequences of up to 224 keys (every shape the MF-MDM launchers produce:
+// T <= 196 -> S <= 201).
+//
+// Why.  The streaming kernel above keeps ONE 32-key block (16 / 32 KB) in flight per CU and synchronises its 13 waves 7 times;
+// with K / V^T coming out of the Infinity Cache (the QKV GEMM has just written them) a block takes 2 - 4 us to arrive and only
+// 0.3 (bf16) - 1.3 us (split modes) to multiply: rocprofv3 PMC, profiles/r02/pmc_attention_*: matrix pipe busy 14 - 29 %,
+// SQ_WAIT_ANY 43 %, no bank conflicts, 3.4 TB/s.  It is bound by exposed load latency, not by MFMA, LDS or bandwidth.
+//
+// Here all of K of the (clip, head) is requested in ONE burst (53 KB bf16, 106 KB split modes: >100 LDS-DMA pieces in flight),
+// and as many 32-key blocks of V^T as fit next to it (all 7 in bf16 and at hd = 64; 3 at hd = 128 in the split modes) in a
+// second burst that flies under the S^T = K Q^T products.  Every wave computes the scores of its 16 queries against ALL keys
+// (14 accumulator tiles), so the softmax is the exact two-pass one of the reference (max over all keys, then exp2 / sum) - no
+// running maximum, no rescale - and the waves meet at three barriers in total (K landed; V^T landed and K released; and, when
+// V^T did not fit beside K, its remaining blocks, which are fetched into K's space under the first P V products).  Between
+// the barriers the waves drift apart, so one wave's MFMAs cover another's exp2 / hi-lo splits / LDS reads.
+// Same operand layouts, swizzles, MFMA operand order and output as the streaming kernel; per query the result depends only on
+// that query's row of Q and the clip's K / V (batch- and split-invariant).
+// ------------------------------------------------------------------------------------------------------------------------
+// logical index with XCD-contiguous chunks (the bijection of tamf_gemm.h's xcd_remap: blocks b and b + 8 share an XCD)
+TAMF_DEV int attn_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <class Op, int HD, int NKB_>
+struct AttnRes {
+  typedef AttnCfg<Op, HD> C;
+  typedef AttnBlock<Op, HD> BLK;
+  static constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16;
+  static constexpr int NKB = NKB_, NKT = 2 * NKB;        // key blocks / key tiles held in registers (S <= 32 NKB)
+  static constexpr int LDS_MAX = 160 * 1024;
+  static_assert(Op::PREC != 0, "16-bit operand modes only (f32 keeps the streaming kernel)");
+
+  // LDS map: [K: Sp rows x KROWB][V^T blocks 0 .. nv1) x V_BYTES]; blocks nv1 .. nkb) later overwrite K from offset 0
+  static int k_bytes(int Sp) { return Sp * C::KROWB; }
+  static int nv1(int Sp, int nkb) {
+    const int fit = (LDS_MAX - k_bytes(Sp)) / C::V_BYTES;
+    return fit < nkb ? fit : nkb;
+  }
+  static bool fits(int S, int Sp) {
+    const int nkb = (S + 31) / 32;
+    if (nkb > NKB || Sp > NKT * 16 || (k_bytes(Sp) % 1024) != 0) return false;
+    const int n1 = nv1(Sp, nkb);
+    return n1 >= 1 && (nkb - n1) * C::V_BYTES <= k_bytes(Sp);
+  }
+  static int smem(int S, int Sp) { return k_bytes(Sp) + nv1(Sp, (S + 31) / 32) * C::V_BYTES; }
+
+  static TAMF_DEV void issue_k(char* Ks, const char* kbase, int Sp, int d, int wave, int nw, int lane) {
+    const int np = (Sp * C::KROWB) >> 10;
+    for (int q = wave; q < np; q += nw) {
+      const int r = q * BLK::K_RPP + lane / BLK::KCH, pc = lane % BLK::KCH;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)r * (2 * d) * EB + BLK::kswz(pc, r) * 16),
+                                       (__attribute__((address_space(3))) void*)(Ks + q * 1024), 16, 0, 0);
+    }
+  }
+  // V^T blocks [kb0, kb1) into dst (block kb at dst + (kb - kb0) * V_BYTES)
+  static TAMF_DEV void issue_v(char* dst, const char* vbase, int kb0, int kb1, int Skp, int wave, int nw, int lane) {
+    const int np = (kb1 - kb0) * BLK::V_PIECES;
+    for (int q = wave; q < np; q += nw) {
+      const int kb = kb0 + q / BLK::V_PIECES, qq = q % BLK::V_PIECES;
+      const int e = qq * BLK::V_RPP + lane / BLK::VCH, pc = lane % BLK::VCH;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((long)e * Skp + kb * 32) * EB + BLK::vswz(pc, e) * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+    }
+  }
+
+  // K fragment i = (key tile i / KG, 128-byte group i % KG) of lane (lr, g): row 16 kt + lr, chunks 8 kg + g and 8 kg + 4 + g.  Both
+  // swizzles depend on the row only through lr (rows of a lane are 16 apart), so the lane's byte offsets inside a key tile are
+  // computed once (koff) and the tile term is a compile-time constant (an immediate offset of the ds_read)
+  struct KOff { int o[KG][2]; };
+  static TAMF_DEV KOff koff(int lr, int g) {
+    KOff k;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      k.o[kg][0] = lr * C::KROWB + BLK::kswz(kg * 8 + g, lr) * 16;
+      k.o[kg][1] = lr * C::KROWB + BLK::kswz(kg * 8 + 4 + g, lr) * 16;
+    }
+    return k;
+  }
+  static TAMF_DEV void kfrag(const char* Ks, int i, const KOff& ko, int4 (&kf)[2]) {
+    const int kt = i / KG, kg = i % KG;
+    kf[0] = *(const int4*)(Ks + kt * (16 * C::KROWB) + ko.o[kg][0]);
+    kf[1] = *(const int4*)(Ks + kt * (16 * C::KROWB) + ko.o[kg][1]);
+  }
+  // phase A: V^T blocks [0, n1) are requested into Vs, then S^T = K Q^T for ALL NKT key tiles, straight-line: tiles past the
+  // clip read rows of the V^T area (any bits) and are overwritten by the key mask.  The K fragments are requested two
+  // (tile, group) steps ahead of the MFMAs that consume them (a wave alone would otherwise expose one LDS latency per step).
+  // Ks / Vs never overlap: the __restrict__ qualifiers keep hipcc from waiting for the V^T requests before the first K
+  // fragment read (as AttnBlock::run).
+  static TAMF_DEV void scores(const char* __restrict__ Ks, char* __restrict__ Vs, const char* vbase, int n1, int Skp, int wave,
+                              int nw, int lane, const int4 (&qf)[KG][2], f32x4 (&st)[NKT], int abl) {
+    const int lr = lane & 15, g = lane >> 4;
+    if (!(abl & 1)) issue_v(Vs, vbase, 0, n1, Skp, wave, nw, lane);
+    constexpr int NF = NKT * KG, LA = 2;
+    const KOff ko = koff(lr, g);
+    int4 kf[LA + 1][2];
+#pragma unroll
+    for (int i = 0; i <= LA; ++i) kf[i][0] = kf[i][1] = qf[0][0];  // (defined contents for the no-read ablation)
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      if (!(abl & 4)) kfrag(Ks, i, ko, kf[i]);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      if (i + LA < NF && !(abl & 4)) kfrag(Ks, i + LA, ko, kf[(i + LA) % (LA + 1)]);
+      __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks each read to its use: read, lgkmcnt(0), three MFMAs, ...)
+      if (i % KG == 0) st[i / KG] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!(abl & 2)) Op::mma(st[i / KG], kf[i % (LA + 1)], qf[i % KG]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // V^T fragment of feature tile nt: row e = 16 nt + lr of the block, chunk g (hi) / 4 + g (lo); again the lane term is hoisted
+  static TAMF_DEV void vfrag(const char* vb, int nt, int vo0, int vo1, int4 (&vf)[2]) {
+    vf[0] = *(const int4*)(vb + nt * (16 * C::VSTR) + vo0);
+    if constexpr (Op::SPLIT) vf[1] = *(const int4*)(vb + nt * (16 * C::VSTR) + vo1);
+  }
+  // O^T += V^T P^T over the key blocks [kb0, kb1) whose V^T blocks lie at Vs (block kb at Vs + (kb - kb0) * V_BYTES); before
+  // that the blocks [dkb0, dkb1) are requested into `dma_dst` (never overlapping Vs)
+  static TAMF_DEV void pv(const char* __restrict__ Vs, char* __restrict__ dma_dst, const char* vbase, int kb0, int kb1, int dkb0,
+                          int dkb1, int Skp, int wave, int nw, int lane, const uint32_t (&ph)[NKB][4], const uint32_t (&pl)[NKB][4],
+                          f32x4 (&o)[NT16], int abl) {
+    const int lr = lane & 15, g = lane >> 4;
+    const int vo0 = lr * C::VSTR + BLK::vswz(g, lr) * 16, vo1 = lr * C::VSTR + BLK::vswz(4 + g, lr) * 16;
+    if (dkb1 > dkb0 && !(abl & 1)) issue_v(dma_dst, vbase, dkb0, dkb1, Skp, wave, nw, lane);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb >= kb0 && kb < kb1) {  // (wave-uniform)
+        const char* vb = Vs + (kb - kb0) * C::V_BYTES;
+        const int4 p_h = make_int4((int)ph[kb][0], (int)ph[kb][1], (int)ph[kb][2], (int)ph[kb][3]);
+        const int4 p_l = make_int4((int)pl[kb][0], (int)pl[kb][1], (int)pl[kb][2], (int)pl[kb][3]);
+        constexpr int LA = 2;
+        int4 vf[LA + 1][2];
+#pragma unroll
+        for (int nt = 0; nt <= LA; ++nt) vf[nt][0] = vf[nt][1] = p_h;  // (defined contents for the no-read ablation)
+#pragma unroll
+        for (int nt = 0; nt < LA; ++nt)
+          if (!(abl & 4)) vfrag(vb, nt, vo0, vo1, vf[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) {
+          if (nt + LA < NT16 && !(abl & 4)) vfrag(vb, nt + LA, vo0, vo1, vf[(nt + LA) % (LA + 1)]);
+          __builtin_amdgcn_sched_barrier(0);
+          const int4 vh = vf[nt % (LA + 1)][0];
+          if (!(abl & 2)) {
+            if constexpr (Op::SPLIT) {
+              const int4 vl = vf[nt % (LA + 1)][1];
+              o[nt] = Op::mfma1(vl, p_h, o[nt]);
+              o[nt] = Op::mfma1(vh, p_l, o[nt]);
+            }
+            o[nt] = Op::mfma1(vh, p_h, o[nt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+};
+
+template <class Op, int HD, int NKB_>
+__global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
+  typedef AttnCfg<Op, HD> C;
+  typedef AttnRes<Op, HD, NKB_> R;
+  constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16, NKB = R::NKB, NKT = R::NKT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, nw = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  // (clip, head) pair of this workgroup: consecutive workgroups go to consecutive XCDs, so the pairs are dealt to the XCDs in
+  // contiguous chunks (xcd_remap) - the clips whose Q | K / V^T rows the QKV GEMM's tiles on that XCD wrote last are then looked
+  // up in the same L2 (aa.abl bit 5 in bench builds: plain order)
+  int bh = blockIdx.y;
+#ifndef TAMF_ATTN_PLAIN_ORDER  // (A/B builds)
+  if (gridDim.x == 1 && !(TAMF_ABL(aa.abl) & 32)) bh = attn_xcd_remap(bh, gridDim.y);
+#endif
+  const int b = bh / aa.H, h = bh % aa.H;
+  const int q0 = (blockIdx.x * nw + wave) * 16;
+  const int S = aa.S, Sp = aa.Sp, d = aa.d;
+  const long row_base = (long)b * Sp;
+  const int nkb = (S + 31) / 32;
+  const int kbytes = Sp * C::KROWB;
+  int n1 = (R::LDS_MAX - kbytes) / C::V_BYTES;
+  n1 = n1 < nkb ? n1 : nkb;
+  char* Ks = smem;
+  char* Vs = smem + kbytes;
+
+  const char* kbase = (const char*)aa.qk + (row_base * (2 * d) + d + h * HD) * EB;
+  const char* vbase = (const char*)aa.vt + ((long)bh * HD) * aa.Skp * EB;
+
+  // Q fragments first (oldest in the vmcnt order), then the K burst
+  int4 qf[KG][2];
+  {
+    int q = q0 + lr;
+    q = q < Sp ? q : Sp - 1;  // (a split of the queries over workgroups may leave the last wave without a tile: it recomputes the last row)
+    const char* qb = (const char*)aa.qk + ((row_base + q) * (2 * d) + h * HD) * EB + g * 16;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      qf[kg][0] = *(const int4*)(qb + kg * 128);
+      qf[kg][1] = *(const int4*)(qb + kg * 128 + 64);
+    }
+  }
+  const int abl = TAMF_ABL(aa.abl);
+  if (!(abl & 1)) R::issue_k(Ks, kbase, Sp, d, wave, nw, lane);
+  __syncthreads();  // K has landed (vmcnt(0) of every wave + barrier)
+
+  // ---- pass 1: scores of this wave's 16 queries against all keys; V^T blocks [0, n1) fly underneath
+  f32x4 st[NKT];
+  R::scores(Ks, Vs, vbase, n1, aa.Skp, wave, nw, lane, qf, st, abl);
+
+  // ---- exact softmax over the keys (per query = per lane column; the 4 lane groups hold disjoint keys)
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+    if (kt * 16 + 15 >= S) {  // (wave-uniform: only the last tiles can hold keys >= S)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kt * 16 + 4 * g + r >= S) st[kt][r] = -1e30f;
+    }
+  float m = -1e30f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) m = fmaxf(m, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+  m = groups_reduce<RedMax>(m);
+  float l = 0.f;
+  uint32_t ph[NKB][4], pl[NKB][4];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (abl & 8) ? st[2 * kb + t][r] : __builtin_amdgcn_exp2f(st[2 * kb + t][r] - m);
+        st[2 * kb + t][r] = p;
+        l += p;
+      }
+    // B fragment element j of lane group g is P[key 4g + j] (j < 4) / P[key 16 + 4g + j - 4] (j >= 4) of the block
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (abl & 8) ph[kb][j] = pl[kb][j] = __builtin_bit_cast(uint32_t, st[2 * kb + (j >> 1)][(2 * j) & 3]);
+      else Op::split2(st[2 * kb + (j >> 1)][(2 * j) & 3], st[2 * kb + (j >> 1)][((2 * j) & 3) + 1], ph[kb][j], pl[kb][j]);
+    }
+  }
+  l = groups_reduce<RedSum>(l);
+
+  f32x4 o[NT16];
+#pragma unroll
+  for (int nt = 0; nt < NT16; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();  // V^T blocks [0, n1) have landed; nobody reads K any more
+  // ---- pass 2: O^T = V^T P^T; the blocks that did not fit beside K are fetched into K's space meanwhile
+  R::pv(Vs, Ks, vbase, 0, n1, n1, nkb, aa.Skp, wave, nw, lane, ph, pl, o, abl);
+  if (n1 < nkb) {
+    __syncthreads();
+    R::pv(Ks, Vs, vbase, n1, nkb, 0, 0, aa.Skp, wave, nw, lane, ph, pl, o, abl);
+  }
+
+  // ---- output: the wave's 16 x HD tile goes through a lane-private 2-KiB LDS slot per 128-byte row group, so that a store
+  // instruction writes whole 128-byte lines (8 rows x 128 B per dwordx4 wave-instruction) instead of 8-byte pieces of 16 rows:
+  // the row-per-lane form (16 global_store_dwordx2 per lane) cost 7.7 of the kernel's 32 us (tools/attn_bench.py, ablation 16).
+  // The slot lies in the part of LDS nobody reads in the last phase: the first V^T area when the blocks were split, K otherwise.
+  const float inv = 1.0f / l;
+  if ((abl & 16) && inv != 12345.0f) return;
+  constexpr int TPC = Op::SPLIT ? 2 : 4;       // feature tiles per 128-byte row group (32 split elements / 64 bf16)
+  constexpr int NCH = (NT16 + TPC - 1) / TPC, TPCE = NT16 < TPC ? NT16 : TPC;
+  constexpr int RS = 144;                      // slot row stride in bytes (128 + 16: two-way conflicts at worst)
+  char* slot = (n1 < nkb ? Vs : Ks) + wave * (16 * RS);
+  char* gout = (char*)aa.out + ((row_base + q0) * d + h * HD) * EB;
+  const int srow = lane >> 3, spiece = lane & 7;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int tl = 0; tl < TPCE; ++tl) {
+      const int nt = ch * TPC + tl;
+      const float v0 = o[nt][0] * inv, v1 = o[nt][1] * inv, v2 = o[nt][2] * inv, v3 = o[nt][3] * inv;
+      uint32_t h0, l0, h1, l1;
+      Op::split2(v0, v1, h0, l0);
+      Op::split2(v2, v3, h1, l1);
+      char* sp = slot + lr * RS + (tl * 16 + 4 * g) * 2;  // element c = 16 tl + 4 g of the group: hi at 2 c, lo 64 bytes further
+      *(uint2*)sp = make_uint2(h0, h1);
+      if constexpr (Op::SPLIT) *(uint2*)(sp + 64) = make_uint2(l0, l1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 8 + srow;
+      const int4 w = *(const int4*)(slot + row * RS + spiece * 16);
+      if (q0 + row < Sp && (NT16 >= TPC || spiece * 16 < NT16 * 16 * (Op::SPLIT ? 4 : 2)))
+        *(int4*)(gout + (long)row * d * EB + ch * 128 + spiece * 16) = w;
+    }
   }
 }

@@ -213,7 +213,7 @@ static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too,
-// 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds
+// 512 = streaming attention kernel in the 16-bit modes too, 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -392,6 +392,12 @@ static hipError_t prepare_all() {
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 128>::SMEM)) != hipSuccess) return e;
+  if constexpr (Op::PREC != 0) {
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -407,6 +413,23 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
   constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;
+  // 16-bit modes, up to 224 keys: K resident in LDS, exact two-pass softmax, three barriers (tamf_attn.h AttnRes); the streaming
+  // kernel serves f32, longer sequences and the A/B switch (selection bit 512)
+  if constexpr (Op::PREC != 0) {
+    if (!(g_sel & 512)) {
+#define TAMF_TRY_RES(HD_, NKB_)                                                                            \
+  if (hd == HD_ && AttnRes<Op, HD_, NKB_>::fits(aa.S, aa.Sp)) {                                           \
+    const int lds = AttnRes<Op, HD_, NKB_>::smem(aa.S, aa.Sp);                                             \
+    hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nw * 64), lds, st, aa);                \
+    return hipGetLastError();                                                                              \
+  }
+      TAMF_TRY_RES(64, 4)   // up to 128 keys (the dataset's clips: T <= 160 needs 7)
+      TAMF_TRY_RES(64, 7)   // up to 224 keys
+      TAMF_TRY_RES(128, 4)
+      TAMF_TRY_RES(128, 7)
+#undef TAMF_TRY_RES
+    }
+  }
   if (hd == 64) {
     hipLaunchKernelGGL((attn_kernel<Op, 64>), grid, dim3(nw * 64), smem64, st, aa);
   } else if (hd == 128) {
@@ -891,7 +914,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       }
     }
     {
-      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H};
+      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H, 0};
       HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
       mark("attention", 4.0 * B * (double)S * S * dd);
     }
@@ -1275,7 +1298,7 @@ static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* 
   (void)hipMemsetAsync(vt, 0, vt_n * Op::EB, st);
   const float qscale = 1.4426950408889634f / sqrtf((float)hd);
   hipLaunchKernelGGL((qkv_pack_kernel<Op>), grid1d(M * 3 * d), dim3(256), 0, st, qkv, qk, vt, B, S, Sp, Skp, H, hd, qscale);
-  AttnArgs<Op> aa{qk, vt, oo, S, Sp, Skp, d, H};
+  AttnArgs<Op> aa{qk, vt, oo, S, Sp, Skp, d, H, 0};
   hipError_t e = launch_attn<Op>(aa, B, hd, st);
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("attn launch: ") + hipGetErrorString(e));
   hipLaunchKernelGGL((unpack_operand_kernel<Op>), grid1d(M * d), dim3(256), 0, st, oo, of, M, d, d);
@@ -1369,6 +1392,53 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
     return fail(nullptr, TAMF_ERR_HIP, std::string("bench gemm: ") + hipGetErrorString(e != hipSuccess ? e : se));
   *ms_out = ms / iters;
   return 0;
+}
+
+// attention alone on random operands resident in HBM (tools/attn_bench.py): average ms of `iters` launches
+template <class Op>
+static int bench_attn_impl(int B, int S, int H, int hd, int iters, int abl, float* ms_out, hipStream_t st) {
+  typedef typename Op::elem_t E;
+  if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
+  const int d = H * hd, Sp = round_up(S, 8), Skp = round_up(S, 32);
+  const long M = (long)B * Sp, qk_n = M * 2 * d, vt_n = (long)B * d * Skp, o_n = M * d;
+  TmpBufs tb;
+  E* qk = (E*)tb.get((size_t)qk_n * Op::EB);
+  E* vt = (E*)tb.get((size_t)vt_n * Op::EB);
+  E* oo = (E*)tb.get((size_t)o_n * Op::EB);
+  if (!qk || !vt || !oo) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(qk_n / 8), dim3(256), 0, st, qk, qk_n, 5u);
+  hipLaunchKernelGGL((fill_operand_kernel<Op>), grid1d(vt_n / 8), dim3(256), 0, st, vt, vt_n, 6u);
+  AttnArgs<Op> aa{qk, vt, oo, S, Sp, Skp, d, H, abl};
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
+  hipError_t e = hipSuccess;
+  for (int it = -2; it < iters && e == hipSuccess; ++it) {
+    if (it == 0) (void)hipEventRecord(e0, st);
+    e = launch_attn<Op>(aa, B, hd, st);
+  }
+  (void)hipEventRecord(e1, st);
+  hipError_t se = hipStreamSynchronize(st);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess || se != hipSuccess)
+    return fail(nullptr, TAMF_ERR_HIP, std::string("bench attention: ") + hipGetErrorString(e != hipSuccess ? e : se));
+  *ms_out = ms / iters;
+  return 0;
+}
+
+extern "C" int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t iters, int32_t abl,
+                                    int32_t tuning, float* ms_out, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0 || !(hd == 64 || hd == 128) || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
+  if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
+  const int saved_rot = g_krot, saved_sel = g_sel;
+  tamf_set_gemm_tuning(tuning);
+  int rc = 0;
+  TAMF_WITH_OP(precision, rc = bench_attn_impl<Op>(B, S, H, hd, iters, abl, ms_out, (hipStream_t)stream));
+  g_krot = saved_rot;
+  g_sel = saved_sel;
+  return rc;
 }
 
 extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
