@@ -298,6 +298,13 @@ struct EpiSeqRows {
   float* xout;  // [rows][d] fp32 or null
   typename Op::elem_t* xop;  // operand planes or null
   int d, Tdiv, Sp, P;
+  // the rows the encoder input needs besides the frame tokens, written by the tile that holds a clip's first frame (one launch
+  // less per step than a separate kernel): prefix row 0 = timestep-embedding table row of the clip's current t (has_t), prefix
+  // rows 1.. = the step-invariant tokens, pad rows [S, Sp) = 0.  pstatic == null: none (the timestep-table build).
+  const float* pstatic;  // [B][P - has_t][d]
+  const float* temb;     // [n_t][d]
+  const int* tcur;
+  int has_t, S;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -318,6 +325,29 @@ struct EpiSeqRows {
       for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
       if (xout) g_store8(xout + orow * d + gn, v);
       if (xop) Op::template store_rc<8>(xop, orow * d + gn, v, am);
+    }
+    if (pstatic) {
+      const int rows_per_clip = P + (Sp - S);
+      const int m1 = m0 + BM < M ? m0 + BM : M;
+      for (int b = (m0 + Tdiv - 1) / Tdiv; b * Tdiv < m1; ++b) {  // clips whose first frame row lies in this tile
+        for (int it = tid; it < rows_per_clip * VPR; it += NT) {
+          const int j = it / VPR, c = n0 + (it % VPR) * 8;
+          float v[8];
+          int s;
+          if (j < P) {
+            s = j;
+            const float* src = (has_t && j == 0) ? temb + (long)tcur[b] * d : pstatic + ((long)b * (P - has_t) + (j - has_t)) * d;
+            g_load8(src + c, v);
+          } else {
+            s = S + (j - P);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+          }
+          const long o = ((long)b * Sp + s) * d + c;
+          g_store8(xout + o, v);
+          Op::template store_rc<8>(xop, o, v, am);
+        }
+      }
     }
     Op::range_flag(am);
   }
@@ -439,8 +469,28 @@ struct EpiHead {
   const float* sigma;
   int n_steps;
   const LoopParams* __restrict__ lp;  // HEAD_DDPM only
+  // sampling loop only (else null): the step counter of every clip is decremented by the LAST workgroup of the launch to finish
+  // (one launch less per step).  Every workgroup reads tcur at the head of its epilogue and takes a ticket at its end, so the
+  // workgroup that draws the last ticket knows that all reads of this step are done; it also resets the ticket word.
+  unsigned* ticket;
+  int* tcur_rw;
+  int n_clips;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid);
+    if (ticket) {
+      __syncthreads();  // every thread of this workgroup has read tcur
+      if (tid == 0) {
+        const unsigned old = atomicAdd(ticket, 1u);
+        if (old == gridDim.x - 1) {
+          for (int b = 0; b < n_clips; ++b) tcur_rw[b] -= 1;
+          __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run_rows(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;

@@ -73,7 +73,12 @@ struct ClipGemmArgs {
   int ldw;
   int n_clips, Sp;  // A has n_clips * Sp rows; a tile covers rows [b*Sp, b*Sp + Sp)
   int N, K;
-  int n_tiles;      // n_clips * (N / BN)
+  int n_tiles;      // (row parts of all clips) * (N / BN)
+  // > 0: every clip is cut into TWO row parts, rows [0, split_rows) and [split_rows, Sp), each a tile of its own (the kernel is
+  // then instantiated with NSUB = split_rows / 16 row tiles; the second part's rows past the clip are clamped on the load side and
+  // skipped on the store side like a clip's own padding).  Used when whole-clip tiles would fill at most half of the CUs
+  // (32 clips per GPU): same products in the same K order per output element, i.e. the same bits as the whole-clip tiles.
+  int split_rows;
   int abl;          // kernel-benchmark ablations (-DTAMF_BENCH builds only, TAMF_ABL) (tools/kbench.py): 1 = no loads after the first K tiles, 2 = no MFMAs, 4 = no epilogue,
                     // 8 = no activation, 16 = every row tile is stored into the rows of the first one (no new lines to write back)
 };
@@ -128,7 +133,19 @@ TAMF_DEV int clip_wperm(int s) {
 struct ClipSrc {
   unsigned a0, a_last, w0;  // byte offsets from A / W of the lane's row in piece nq (A: unclamped; clamped last row; W: permuted)
   int hq;                   // 32-row block of W piece nq + 4 i: i + hq
+  int rows;                 // valid rows of the tile's row part
 };
+// row part `v` of the launch: first row (in rows of A) and number of valid rows
+template <class Op>
+TAMF_DEV void clip_part(const ClipGemmArgs<Op>& ga, int v, int& base, int& rows) {
+  if (ga.split_rows > 0) {
+    base = (v >> 1) * ga.Sp + (v & 1) * ga.split_rows;
+    rows = (v & 1) ? ga.Sp - ga.split_rows : ga.split_rows;
+  } else {
+    base = v * ga.Sp;
+    rows = ga.Sp;
+  }
+}
 template <class Op, class C>
 TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int nq, int prow, int pch) {
   const int r0 = nq * 8 + prow;
@@ -136,8 +153,10 @@ TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int nq, int
   const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
   const int e = nq * 8 - C::MT;  // staged W row of (virtual) piece nq, lane row 0: negative
   ClipSrc s;
-  s.a0 = (unsigned)(b * ga.Sp + r0) * ldaB + swz;
-  s.a_last = (unsigned)(b * ga.Sp + ga.Sp - 1) * ldaB + swz;
+  int base;
+  clip_part(ga, b, base, s.rows);
+  s.a0 = (unsigned)(base + r0) * ldaB + swz;
+  s.a_last = (unsigned)(base + s.rows - 1) * ldaB + swz;
   s.w0 = (unsigned)(n0 + clip_wperm<C::CHUNK>((e & 31) + prow)) * ldwB + swz;
   s.hq = e >> 5;
   return s;
@@ -156,7 +175,7 @@ TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, i
     if ((i + 1) * QS <= C::NPIECE || q < C::NPIECE) {
       const char* src;
       if (q < C::A_PIECES) {
-        const unsigned o = (q * 8 + prow < ga.Sp) ? s.a0 + (unsigned)(QS * 8 * i) * ldaB : s.a_last;
+        const unsigned o = (q * 8 + prow < s.rows) ? s.a0 + (unsigned)(QS * 8 * i) * ldaB : s.a_last;
         src = Ab + o;
       } else {
         src = Wb + (s.w0 + (unsigned)clip_wperm<C::CHUNK>(32 * (i + s.hq)) * ldwB);
@@ -525,7 +544,9 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
         } else {
           clip_settle(bi);
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
+          int base, rows;
+          clip_part(ga, b, base, rows);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBX; ++mi)
@@ -578,7 +599,9 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
             else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
           }
           clip_settle(bi);
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, ga.Sp, b * ga.Sp, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
+          int base, rows;
+          clip_part(ga, b, base, rows);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBY; ++mi)

@@ -88,6 +88,7 @@ struct tamf_ctx {
         *objfeat = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
   int* tcur = nullptr;
+  unsigned* ticket = nullptr;  // workgroup ticket of the head kernel (EpiHead: the last one advances the step counter)
   unsigned char* side_dev = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
@@ -304,16 +305,16 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 #define TAMF_CLIP_XSUB_N4 6
 #endif
 template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? TAMF_CLIP_XSUB_N4 : TAMF_CLIP_XSUB_N2; };  // (5 : 8 spills the Y waves at 256 columns)
-template <class Op, int NI, class Epi>
+template <class Op, int NI, class Epi, int NSUB = 13>
 struct ClipLaunch {
   static constexpr int XSUB = ClipXsub<NI>::value;
-  typedef ClipCfg<13, NI, XSUB, Epi::LANE_CHUNK> C;
+  typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   static hipError_t prepare() {
     static bool done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, 13, NI, XSUB, Epi>,
+    hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::BYTES);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
@@ -330,10 +331,22 @@ struct ClipLaunch {
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, n_clips * (N / C::BN), g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
+    static_assert(NSUB == 13 || NSUB == 7, "whole clips (13 row tiles) or the 7 + 6 row-tile parts of one");
+    constexpr int parts = NSUB == 13 ? 1 : 2, split_rows = NSUB == 13 ? 0 : NSUB * 16;
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, parts * n_clips * (N / C::BN), split_rows,
+                        g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
     const int cus = g_wg_slots / 2;
-    hipLaunchKernelGGL((clip_gemm_kernel<Op, 13, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
+    hipLaunchKernelGGL((clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
+  }
+  // row-part tiles (NSUB = 7): when whole-clip tiles would use at most half of the CUs and the parts fit one round
+  static bool applies_parts(int n_clips, int Sp, int N, int K) {
+    if (g_sel & 1) return false;
+    if (Sp != 208 || N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
+    const int KT = (K * Op::EB) / GEMM_BKB;
+    if (KT < 2 || (KT & 1)) return false;
+    const int cus = g_wg_slots / 2, whole = n_clips * (N / C::BN);
+    return whole * 2 <= cus;
   }
 };
 
@@ -387,6 +400,7 @@ static hipError_t prepare_all() {
   if ((e = ClipLaunch<Op, 4, EpiQK<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiVt<Op>>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32, 7>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
@@ -540,6 +554,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
   A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
   A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->ticket, 64, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
   A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
   if (rc) return bail(rc);
@@ -726,7 +741,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, d, ACT_SILU};
     HIPCHK(ctx, gemm128<OpF32>(g1, e1, st));
     GemmArgs<OpF32> g2{tmp, d, (const float*)ctx->Wt2_f32.p, d, ctx->n_t, d, d, 0};
-    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, d, 0x7FFFFFFF, 0, 0};
+    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, d, 0x7FFFFFFF, 0, 0, nullptr, nullptr, nullptr, 0, 0};
     HIPCHK(ctx, gemm128<OpF32>(g2, e2, st));
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
@@ -868,12 +883,6 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     ctx->prof_names.push_back(name);
     ctx->prof_flops.push_back(flops);
   };
-  {
-    const int rows = P + (Sp - S);
-    hipLaunchKernelGGL((prefix_fill_kernel<Op>), grid1d((long)B * rows * (d / 8)), dim3(256), 0, st, ctx->X, (E*)ctx->X_op.p,
-                       ctx->temb, ctx->tcur, ctx->pstatic, B, d, P, ctx->has_t, S, Sp);
-    mark("prefix_fill", ctx->has_t ? B * 4.0 * dd * dd : 0.0);
-  }
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
     GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->XK, (const E*)ctx->Wfused.p, ctx->XK, B * T, d, ctx->XK, 0};
     EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, d, ACT_SILU};
@@ -883,9 +892,10 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   }
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
-    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P};
+    // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-    mark("gemm_input_merge2", BT * 2.0 * dd * dd);
+    mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
   for (int l = 0; l < ctx->L; ++l) {
@@ -956,7 +966,11 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       if ((Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
-        if (clip2)
+        // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 row-tile parts of every clip
+        // as tiles of their own fill the round (58 -> ~40 us; same bits)
+        if (clip2 && ClipLaunch<Op, 2, EpiStoreF32, 7>::applies_parts(B, Sp, d, ff))
+          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, 7>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
+        else if (clip2)
           HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
         else
           HIPCHK(ctx, gemm128<Op>(ga, ep, st));
@@ -1074,13 +1088,14 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
                      (long long)clip_base);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
+  h.ticket = ctx->ticket;  // the head kernel's last workgroup decrements the step counter (no separate launch)
+  h.tcur_rw = ctx->tcur;
+  h.n_clips = B;
+  HIPCHK(ctx, hipMemsetAsync(ctx->ticket, 0, sizeof(unsigned), st));
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
                      (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {
-    for (int i = 0; i < N; ++i) {
-      TRY(enqueue_step<Op>(ctx, st, h));
-      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B);
-    }
+    for (int i = 0; i < N; ++i) TRY(enqueue_step<Op>(ctx, st, h));
   } else {
     // G consecutive steps per graph (the largest divisor of N up to 16: 10 for N = 1000 -> 100 graph launches per loop);
     // the sequence is step-agnostic (device-side step counter) and seed-agnostic (LoopParams), so it is captured once per
@@ -1094,10 +1109,7 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
       TRY(retire_graph(ctx));
       HIPCHK(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
       int rc = 0;
-      for (int g = 0; g < G && rc == 0; ++g) {
-        rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
-        hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, ctx->cap_stream, ctx->tcur, B);
-      }
+      for (int g = 0; g < G && rc == 0; ++g) rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
       hipError_t ee = hipStreamEndCapture(ctx->cap_stream, &ctx->graph);
       if (rc) return rc;
       HIPCHK(ctx, ee);

@@ -70,40 +70,6 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
   Op::range_flag(am);
 }
 
-// Rows the encoder input needs besides the frame tokens, every step: prefix row 0 = timestep-embedding table
-// row of the clip's current t (G), prefix rows 1.. = step-invariant tokens, pad rows [S, Sp) = 0.
-template <class Op>
-__global__ void prefix_fill_kernel(float* __restrict__ X, typename Op::elem_t* Xop,
-                                   const float* __restrict__ temb, const int* __restrict__ tcur,
-                                   const float* __restrict__ pstatic, int B, int d, int P, int has_t, int S, int Sp) {
-  const int rows_per_clip = P + (Sp - S);
-  const int CG = d / 8;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * rows_per_clip * CG) return;
-  const int cg = idx % CG, br = idx / CG;
-  const int b = br / rows_per_clip, j = br % rows_per_clip;
-  float v[8];
-  int s;
-  if (j < P) {
-    s = j;
-    const float* src;
-    if (has_t && j == 0) src = temb + (long)tcur[b] * d;
-    else src = pstatic + ((long)b * (P - has_t) + (j - has_t)) * d;
-    const float4 a = *(const float4*)(src + cg * 8), c = *(const float4*)(src + cg * 8 + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-  } else {
-    s = S + (j - P);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0.f;
-  }
-  const long o = ((long)b * Sp + s) * d + cg * 8;
-  *(float4*)(X + o) = make_float4(v[0], v[1], v[2], v[3]);
-  *(float4*)(X + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  float am = 0.f;
-  Op::template store_rc<8>(Xop, o, v, am);
-  Op::range_flag(am);
-}
-
 // y = LayerNorm(resid + c) * gamma + beta, one wave per row of D = 64 * VPL columns; writes fp32 + operand
 // (second half of the two-kernel form of a LayerNorm-fused GEMM: tamf_hip.hip, FFN2)
 template <class Op, int VPL>
@@ -176,10 +142,6 @@ __global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float
     lp->seed = seed;
     lp->clip_base = clip_base;
   }
-}
-__global__ void advance_t_kernel(int* tcur, int B) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tcur[i] -= 1;
 }
 
 // out[o][i] = mean_m in[o][m][i]   (torch.mean: sum / n)
