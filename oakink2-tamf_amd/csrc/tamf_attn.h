@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnArgs<Op> aa) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Resident-K attention for the 16-bit modes and sequences of up to 224 keys (every shape the MF-MDM launchers produce:
+// Resident-K attention for sequences of up to 224 keys (every shape the MF-MDM launchers produce:
 // T <= 196 -> S <= 201).
 //
 // Why.  The streaming kernel above keeps ONE 32-key block (16 / 32 KB) in flight per CU and synchronises its 13 waves 7 times;
@@ -293,7 +293,7 @@ struct AttnRes {
   static constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16;
   static constexpr int NKB = NKB_, NKT = 2 * NKB;        // key blocks / key tiles held in registers (S <= 32 NKB)
   static constexpr int LDS_MAX = 160 * 1024;
-  static_assert(Op::PREC != 0, "16-bit operand modes only (f32 keeps the streaming kernel)");
+  static constexpr bool TWO = Op::SPLIT || Op::PREC == 0;  // two 16-byte V^T fragments per lane and feature tile (hi | lo, or f32's two key groups)
 
   // LDS map: [K: Sp rows x KROWB][V^T blocks 0 .. nv1) x V_BYTES]; blocks nv1 .. nkb) later overwrite K from offset 0
   static int k_bytes(int Sp) { return Sp * C::KROWB; }
@@ -375,7 +375,7 @@ struct AttnRes {
   // V^T fragment of feature tile nt: row e = 16 nt + lr of the block, chunk g (hi) / 4 + g (lo); again the lane term is hoisted
   static TAMF_DEV void vfrag(const char* vb, int nt, int vo0, int vo1, int4 (&vf)[2]) {
     vf[0] = *(const int4*)(vb + nt * (16 * C::VSTR) + vo0);
-    if constexpr (Op::SPLIT) vf[1] = *(const int4*)(vb + nt * (16 * C::VSTR) + vo1);
+    if constexpr (TWO) vf[1] = *(const int4*)(vb + nt * (16 * C::VSTR) + vo1);
   }
   // O^T += V^T P^T over the key blocks [kb0, kb1) whose V^T blocks lie at Vs (block kb at Vs + (kb - kb0) * V_BYTES); before
   // that the blocks [dkb0, dkb1) are requested into `dma_dst` (never overlapping Vs)
@@ -404,12 +404,27 @@ struct AttnRes {
           __builtin_amdgcn_sched_barrier(0);
           const int4 vh = vf[nt % (LA + 1)][0];
           if (!(abl & 2)) {
-            if constexpr (Op::SPLIT) {
-              const int4 vl = vf[nt % (LA + 1)][1];
-              o[nt] = Op::mfma1(vl, p_h, o[nt]);
-              o[nt] = Op::mfma1(vh, p_l, o[nt]);
+            if constexpr (Op::PREC == 0) {
+              // f32: k-slot of lane group g in MFMA (t, r) is key 16 t + 4 g + r; ph / pl carry the probabilities of t = 0 / 1 as floats
+              // (the probabilities are taken from the scalar array elements: bit-casting the components of the int4 temporaries
+              //  p_h / p_l read component 0 four times with hipcc 7.2 - cf. groups_reduce in tamf_device.h)
+              const int4 v1 = vf[nt % (LA + 1)][1];
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vh.x), __builtin_bit_cast(float, ph[kb][0]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vh.y), __builtin_bit_cast(float, ph[kb][1]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vh.z), __builtin_bit_cast(float, ph[kb][2]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(vh.w), __builtin_bit_cast(float, ph[kb][3]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(v1.x), __builtin_bit_cast(float, pl[kb][0]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(v1.y), __builtin_bit_cast(float, pl[kb][1]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(v1.z), __builtin_bit_cast(float, pl[kb][2]), o[nt], 0, 0, 0);
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(v1.w), __builtin_bit_cast(float, pl[kb][3]), o[nt], 0, 0, 0);
+            } else {
+              if constexpr (Op::SPLIT) {
+                const int4 vl = vf[nt % (LA + 1)][1];
+                o[nt] = Op::mfma1(vl, p_h, o[nt]);
+                o[nt] = Op::mfma1(vh, p_l, o[nt]);
+              }
+              o[nt] = Op::mfma1(vh, p_h, o[nt]);
             }
-            o[nt] = Op::mfma1(vh, p_h, o[nt]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -497,8 +512,15 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
     // B fragment element j of lane group g is P[key 4g + j] (j < 4) / P[key 16 + 4g + j - 4] (j >= 4) of the block
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (abl & 8) ph[kb][j] = pl[kb][j] = __builtin_bit_cast(uint32_t, st[2 * kb + (j >> 1)][(2 * j) & 3]);
-      else Op::split2(st[2 * kb + (j >> 1)][(2 * j) & 3], st[2 * kb + (j >> 1)][((2 * j) & 3) + 1], ph[kb][j], pl[kb][j]);
+      if constexpr (Op::PREC == 0) {  // f32: the probabilities themselves, key tile 2 kb in ph, 2 kb + 1 in pl
+        // (copied to scalars first: __builtin_bit_cast straight from a vector element reads element 0 with hipcc 7.2, tamf_device.h)
+        const float p0 = st[2 * kb][j], p1 = st[2 * kb + 1][j];
+        ph[kb][j] = __builtin_bit_cast(uint32_t, p0);
+        pl[kb][j] = __builtin_bit_cast(uint32_t, p1);
+      } else {
+        if (abl & 8) { const float pa = st[2 * kb + (j >> 1)][(2 * j) & 3]; ph[kb][j] = pl[kb][j] = __builtin_bit_cast(uint32_t, pa); }
+        else Op::split2(st[2 * kb + (j >> 1)][(2 * j) & 3], st[2 * kb + (j >> 1)][((2 * j) & 3) + 1], ph[kb][j], pl[kb][j]);
+      }
     }
   }
   l = groups_reduce<RedSum>(l);
@@ -521,7 +543,7 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
   // The slot lies in the part of LDS nobody reads in the last phase: the first V^T area when the blocks were split, K otherwise.
   const float inv = 1.0f / l;
   if ((abl & 16) && inv != 12345.0f) return;
-  constexpr int TPC = Op::SPLIT ? 2 : 4;       // feature tiles per 128-byte row group (32 split elements / 64 bf16)
+  constexpr int TPC = Op::EB == 4 ? 2 : 4;     // feature tiles per 128-byte row group (32 f32 or split elements / 64 bf16)
   constexpr int NCH = (NT16 + TPC - 1) / TPC, TPCE = NT16 < TPC ? NT16 : TPC;
   constexpr int RS = 144;                      // slot row stride in bytes (128 + 16: two-way conflicts at worst)
   char* slot = (n1 < nkb ? Vs : Ks) + wave * (16 * RS);
@@ -533,18 +555,24 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
     for (int tl = 0; tl < TPCE; ++tl) {
       const int nt = ch * TPC + tl;
       const float v0 = o[nt][0] * inv, v1 = o[nt][1] * inv, v2 = o[nt][2] * inv, v3 = o[nt][3] * inv;
-      uint32_t h0, l0, h1, l1;
-      Op::split2(v0, v1, h0, l0);
-      Op::split2(v2, v3, h1, l1);
-      char* sp = slot + lr * RS + (tl * 16 + 4 * g) * 2;  // element c = 16 tl + 4 g of the group: hi at 2 c, lo 64 bytes further
-      *(uint2*)sp = make_uint2(h0, h1);
-      if constexpr (Op::SPLIT) *(uint2*)(sp + 64) = make_uint2(l0, l1);
+      if constexpr (Op::PREC == 0) {
+        // (written with the integer vector type the read-back below uses: a float4 store and an int4 load of the same bytes do not
+        //  alias under the type-based rules, and hipcc then moves the load ahead of the store)
+        *(int4*)(slot + lr * RS + (tl * 16 + 4 * g) * 4) = make_int4(as_i(v0), as_i(v1), as_i(v2), as_i(v3));
+      } else {
+        uint32_t h0, l0, h1, l1;
+        Op::split2(v0, v1, h0, l0);
+        Op::split2(v2, v3, h1, l1);
+        char* sp = slot + lr * RS + (tl * 16 + 4 * g) * 2;  // element c = 16 tl + 4 g of the group: hi at 2 c, lo 64 bytes further
+        *(int2*)sp = make_int2((int)h0, (int)h1);
+        if constexpr (Op::SPLIT) *(int2*)(sp + 64) = make_int2((int)l0, (int)l1);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = i * 8 + srow;
       const int4 w = *(const int4*)(slot + row * RS + spiece * 16);
-      if (q0 + row < Sp && (NT16 >= TPC || spiece * 16 < NT16 * 16 * (Op::SPLIT ? 4 : 2)))
+      if (q0 + row < Sp && (NT16 >= TPC || spiece * 16 < NT16 * 16 * Op::EB))
         *(int4*)(gout + (long)row * d * EB + ch * 128 + spiece * 16) = w;
     }
   }

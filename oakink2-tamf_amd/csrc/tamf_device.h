@@ -105,6 +105,9 @@ TAMF_DEV float erf_as(float x) {
   const float y = fmaf(-p * t, e, 1.0f);
   return copysignf(y, x);
 }
+// (measured and dropped, round 3: GELU(x) = max(x, 0) - |x| q(|x|) with the 7.1.26 polynomial's coefficients halved - three VALU
+//  instructions fewer per element and 3.3e-7 instead of 4.7e-7 max abs error on paper, but the FFN1 launch got SLOWER, 81.2 -> 84.9 us
+//  (f16x3, tools/kbench.py, two builds alternating on one box): the epilogue's time is not its instruction count)
 TAMF_DEV float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // Per-loop inputs of the fused DDPM update.  They live in device memory and are read by the kernel, so the captured graph

@@ -71,6 +71,14 @@ TAMF_DEV void g_loadn(const float* p, float (&v)[N]) {
     v[j] = a.x; v[j + 1] = a.y; v[j + 2] = a.z; v[j + 3] = a.w;
   }
 }
+// a (free) register use that makes the compiler wait for loaded values HERE, once, ahead of a loop that stores: vmcnt retires in
+// order, so a wait for a load that the compiler places at its first use INSIDE such a loop also waits for the previous
+// iteration's stores - an epilogue then runs one store round trip per row (seen in the ISA as s_waitcnt vmcnt(0) between stores)
+template <int N>
+TAMF_DEV void settle(const float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" ::"v"(v[j]));
+}
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
   gst16f(p, v[0], v[1], v[2], v[3]);
   gst16f(p + 4, v[4], v[5], v[6], v[7]);
@@ -116,12 +124,39 @@ struct EpiBiasAct {
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;
     float am = 0.f;
-    for (int row = tid / VPR; row < BM; row += RSTEP) {
-      const int gr = m0 + row;
-      if (gr >= M) break;
-      float v[8];
-      ct_load8(Ct, LDC, row, col, v);
-      finish_act<8>(act, gr, gn, v, cc.bi, am);
+    if (rowadd) {
+      // the row terms of all of this thread's rows are requested (and waited for) before the first store: a load issued behind
+      // stores waits for them (vmcnt retires in order) - one store round trip per row otherwise (input_merge.0)
+      constexpr int NR = BM / RSTEP;
+      static_assert(BM % RSTEP == 0, "rows per thread");
+      float ra[NR][8];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        int gr = m0 + tid / VPR + i * RSTEP;
+        gr = gr < M ? gr : M - 1;
+        g_load8(rowadd + (long)gr * ld_rowadd + gn, ra[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NR; ++i) settle(ra[i]);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int row = tid / VPR + i * RSTEP, gr = m0 + row;
+        if (gr < M) {
+          float v[8];
+          ct_load8(Ct, LDC, row, col, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (v[j] + cc.bi[j]) + ra[i][j];
+          act_store<8>(act, gr, gn, v, am);
+        }
+      }
+    } else {
+      for (int row = tid / VPR; row < BM; row += RSTEP) {
+        const int gr = m0 + row;
+        if (gr >= M) break;
+        float v[8];
+        ct_load8(Ct, LDC, row, col, v);
+        finish_act<8>(act, gr, gn, v, cc.bi, am);
+      }
     }
     OutOp::range_flag(am);
   }
@@ -140,6 +175,11 @@ struct EpiBiasAct {
 #pragma unroll
       for (int j = 0; j < N; ++j) v[j] += b[j];
     }
+    act_store<N>(a, gr, gn, v, am);
+  }
+  // activation + operand store (the sum is complete)
+  template <int N>
+  TAMF_DEV void act_store(int a, int gr, int gn, float (&v)[N], float& am) const {
     if (a == ACT_SILU) {
       if constexpr (OutOp::PREC == 0) {
 #pragma unroll
@@ -232,15 +272,24 @@ struct EpiQKV {
       const int col = (tid % VPR) * 8, gn = n0 + col;
       float b[8];
       g_load8(bias + gn, b);
+      settle(b);
       float am = 0.f;
-      for (int row = tid / VPR; row < BM; row += RSTEP) {
-        const int gr = m0 + row;
-        if (gr >= M) break;
-        float v[8];
-        ct_load8(Ct, LDC, row, col, v);
+      // rows in batches of 4: the C-tile reads of a batch are requested together (one LDS latency per batch instead of one per row:
+      // left to itself the loop is read - wait - convert - store, row by row)
+      constexpr int NR = BM / RSTEP, RB = NR % 4 == 0 ? 4 : (NR % 2 == 0 ? 2 : 1);
+      for (int r0 = 0; r0 < NR; r0 += RB) {
+        float v[RB][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (v[j] + b[j]) * sc;
-        Op::template store_rc<8>(qk, (long)gr * (2 * d) + gn, v, am);
+        for (int i = 0; i < RB; ++i) ct_load8(Ct, LDC, tid / VPR + (r0 + i) * RSTEP, col, v[i]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int gr = m0 + tid / VPR + (r0 + i) * RSTEP;
+          if (gr < M) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] + b[j]) * sc;
+            Op::template store_rc<8>(qk, (long)gr * (2 * d) + gn, v[i], am);
+          }
+        }
       }
       Op::range_flag(am);
     } else if constexpr (Op::PREC == 0) {
@@ -259,28 +308,95 @@ struct EpiQKV {
         Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
       }
     } else {
-      // 16-bit modes: V^T is key-permuted (vt_key_pos): keys 4q .. 4q+3 of a 16-key group are 4 adjacent positions, the two
-      // groups of a 32-key block interleave in 8-byte steps.  One thread = one such run of 4 keys of one feature; a wave =
-      // 8 features x the 8 runs of one 32-row block, lanes ordered so that the 8 runs of a feature are adjacent: the stores
-      // of a wave are 8 segments of 64 bytes (hi, and again lo) instead of 64 scattered 8-byte pieces, and the column reads
-      // of the C tile are 2-way bank conflicts at worst.
-      static_assert(BM % 32 == 0 && BN % 8 == 0 && NT % 64 == 0, "V^T epilogue tiling");
-      constexpr int NB32 = BM / 32, WITER = NB32 * (BN / 8);  // wave-iterations of the tile
+      // 16-bit modes: V^T is key-permuted (vt_key_pos): inside a 32-key block the keys 4q .. 4q+3 of the two 16-key groups are
+      // adjacent, i.e. 16-byte piece q of the block's 64-byte plane row holds keys {4q .. 4q+3, 16+4q .. 16+4q+3}.
+      static_assert(BM % 32 == 0 && BN % 16 == 0 && NT % 64 == 0, "V^T epilogue tiling");
       const int lane = tid & 63, wv = tid >> 6;
-      const int e_lo = lane >> 3, u_lo = (lane >> 2) & 1, gq = lane & 3;
       float am = 0.f;
-      for (int wi = wv; wi < WITER; wi += NT / 64) {
-        const int col = (wi / NB32) * 8 + e_lo, row0 = (wi % NB32) * 32 + u_lo * 16 + gq * 4;
-        const int gr0 = m0 + row0;
-        if (gr0 >= M) continue;
-        const int eg = n0 - 2 * d + col;
-        const int h = eg / hd, e = eg % hd;
-        const int b = gr0 / Sp, s0 = gr0 % Sp;
-        const float bb = bias[n0 + col];
-        float v[4];
+      if (Sp % 16 == 0 && !Op::SPLIT) {
+        // (bf16; measured on the QKV launch at B = 64 with tools/gemm_timeline.py: tile epilogues median 2.5 -> 1.8 us, p90 6.5 -> 4.0 us,
+        //  launch 34.3 -> 32.0 us.  In the split modes the same scheme - a lane per hi or lo piece, the split computed twice - made the
+        //  V tiles slower, p90 9.2 -> 12.2 us: they keep the 8-byte runs below.)
+        // Clips are whole 16-key groups (T = 196: Sp = 208), so the tile's eight 16-row groups are 16-key groups of (at most two)
+        // clips.  One lane = one 16-byte piece of one feature: lane = piece (q, and hi / lo plane in the split modes) + PPL * feature,
+        // so 8 (4) neighbouring lanes write one whole 128-byte (64-byte) line and a wave-instruction 8 (16) complete lines.  The
+        // two groups of a key block are consecutive row groups of the tile; a group whose partner lies in another tile (odd clips
+        // start in the middle of a 32-row block) is stored as an 8-byte run.  The walk over the row groups is wave-uniform.
+        // (the earlier form stored 8-byte runs only: the V tiles of the QKV launch took 9 us in their epilogue, Q / K tiles 3)
+        constexpr int PPL = Op::SPLIT ? 8 : 4;  // 16-byte pieces per (feature, 32-key block): [hi 4 | lo 4] or 4
+        constexpr int FPW = 64 / PPL;           // features per wave-iteration
+        const int piece = lane % PPL, f_lo = lane / PPL, q = piece & 3;
+        const int plane_off = (Op::SPLIT && piece >= 4) ? 64 : 0;
+        const int ng = (M - m0 < BM ? M - m0 : BM) / 16;  // row groups of this tile that exist (M is a multiple of Sp)
+        constexpr int NGRP = BN / FPW, NFG = (NGRP + NT / 64 - 1) / (NT / 64);  // feature groups of the tile / per wave
+        float bbs[NFG];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;
-        Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
+        for (int i = 0; i < NFG; ++i) {
+          const int fg = wv + i * (NT / 64);
+          bbs[i] = bias[n0 + (fg < NGRP ? fg : 0) * FPW + f_lo];
+        }
+        settle(bbs);
+#pragma unroll
+        for (int i = 0; i < NFG; ++i) {
+          const int fg = wv + i * (NT / 64);
+          if (fg >= NGRP) break;
+          const int col = fg * FPW + f_lo;
+          const int eg = n0 - 2 * d + col;
+          const int h = eg / hd, e = eg % hd;
+          const float bb = bbs[i];
+          for (int r16 = 0; r16 < ng;) {
+            const int gr = m0 + r16 * 16;
+            const int b = gr / Sp, k16 = (gr % Sp) / 16;  // clip and 16-key group
+            const bool pair = !(k16 & 1) && r16 + 1 < ng && (k16 + 1) * 16 < Sp;
+            const long row_idx = ((long)(b * H + h) * hd + e) * Skp + (k16 >> 1) * 32;  // first position of the key block
+            char* pp = (char*)vt + Op::byte_off(row_idx) + plane_off + q * 16;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = Ct[(r16 * 16 + 4 * q + j) * LDC + col] + bb;
+            if (pair) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[4 + j] = Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col] + bb;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[4 + j] = 0.f;
+            }
+            uint32_t wh[4], wl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              Op::split2(v[2 * j], v[2 * j + 1], wh[j], wl[j]);
+              am = fmaxf(fmaxf(am, fabsf(v[2 * j])), fabsf(v[2 * j + 1]));
+            }
+            if (Op::SPLIT && piece >= 4) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) wh[j] = wl[j];
+            }
+            if (pair) {
+              gst16(pp, wh[0], wh[1], wh[2], wh[3]);
+              r16 += 2;
+            } else {  // the group alone: keys 4q .. 4q+3 of group k16 & 1 are bytes [8 (k16 & 1), +8) of the piece
+              gst8(pp + 8 * (k16 & 1), wh[0], wh[1]);
+              r16 += 1;
+            }
+          }
+        }
+      } else {
+        // any other Sp (a multiple of 8): one thread = one run of 4 keys of one feature; a wave = 8 features x the 8 runs of one
+        // 32-row block, lanes ordered so that the 8 runs of a feature are adjacent (8 segments of 64 bytes per store instruction)
+        constexpr int NB32 = BM / 32, WITER = NB32 * (BN / 8);  // wave-iterations of the tile
+        const int e_lo = lane >> 3, u_lo = (lane >> 2) & 1, gq = lane & 3;
+        for (int wi = wv; wi < WITER; wi += NT / 64) {
+          const int col = (wi / NB32) * 8 + e_lo, row0 = (wi % NB32) * 32 + u_lo * 16 + gq * 4;
+          const int gr0 = m0 + row0;
+          if (gr0 >= M) continue;
+          const int eg = n0 - 2 * d + col;
+          const int h = eg / hd, e = eg % hd;
+          const int b = gr0 / Sp, s0 = gr0 % Sp;
+          const float bb = bias[n0 + col];
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;
+          Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
+        }
       }
       Op::range_flag(am);
     }
@@ -313,18 +429,33 @@ struct EpiSeqRows {
     float bi[8];
     g_load8(bias + gn, bi);
     float am = 0.f;
-    for (int row = tid / VPR; row < BM; row += RSTEP) {
-      const int gr = m0 + row;
-      if (gr >= M) break;
-      const int b = gr / Tdiv, tau = gr % Tdiv;
-      const long orow = (long)b * Sp + P + tau;
-      float v[8], pv[8];
-      ct_load8(Ct, LDC, row, col, v);
-      g_load8(pe + (long)tau * pe_stride + gn, pv);
+    // every global load of the epilogue is issued (and waited for: settle) before its first store - vmcnt retires in order, so a
+    // load issued behind stores waits for them
+    constexpr int NR = BM / RSTEP;
+    static_assert(BM % RSTEP == 0, "rows per thread");
+    float pv[NR][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[j];
-      if (xout) g_store8(xout + orow * d + gn, v);
-      if (xop) Op::template store_rc<8>(xop, orow * d + gn, v, am);
+    for (int i = 0; i < NR; ++i) {
+      int gr = m0 + tid / VPR + i * RSTEP;
+      gr = gr < M ? gr : M - 1;
+      g_load8(pe + (long)(gr % Tdiv) * pe_stride + gn, pv[i]);
+    }
+    settle(bi);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) settle(pv[i]);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int row = tid / VPR + i * RSTEP, gr = m0 + row;
+      if (gr < M) {
+        const int b = gr / Tdiv, tau = gr % Tdiv;
+        const long orow = (long)b * Sp + P + tau;
+        float v[8];
+        ct_load8(Ct, LDC, row, col, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[i][j];
+        if (xout) g_store8(xout + orow * d + gn, v);
+        if (xop) Op::template store_rc<8>(xop, orow * d + gn, v, am);
+      }
     }
     if (pstatic) {
       const int rows_per_clip = P + (Sp - S);

@@ -406,7 +406,7 @@ static hipError_t prepare_all() {
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 128>::SMEM)) != hipSuccess) return e;
-  if constexpr (Op::PREC != 0) {
+  {
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -427,9 +427,9 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
   constexpr int smem64 = AttnCfg<Op, 64>::SMEM, smem128 = AttnCfg<Op, 128>::SMEM;
-  // 16-bit modes, up to 224 keys: K resident in LDS, exact two-pass softmax, three barriers (tamf_attn.h AttnRes); the streaming
-  // kernel serves f32, longer sequences and the A/B switch (selection bit 512)
-  if constexpr (Op::PREC != 0) {
+  // up to 224 keys: K resident in LDS, exact two-pass softmax, three barriers (tamf_attn.h AttnRes); the streaming kernel serves
+  // longer sequences and the A/B switch (selection bit 512)
+  {
     if (!(g_sel & 512)) {
 #define TAMF_TRY_RES(HD_, NKB_)                                                                            \
   if (hd == HD_ && AttnRes<Op, HD_, NKB_>::fits(aa.S, aa.Sp)) {                                           \
