@@ -392,10 +392,18 @@ TAMF_DEV void clip_settle(const float (&bi)[NC][CH]) {
 TAMF_DEV void clip_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8]); as a builtin, so that the
 // compiler's own wait-count bookkeeping sees it
+// The counts are compile-time formulas of the instructions issued behind the request that must have landed (PH LDS-DMA pieces,
+// SX epilogue stores): tools/check_clip_stores.py (tests/test_isa_clip_waits.py) disassembles every instantiation and checks that
+// hipcc emitted exactly the stores the formula counts.  -DTAMF_CLIP_SAFE_WAIT turns every counted wait into vmcnt(0) (a debug
+// build to compare bits against: tools/ab_build.sh WORKTREE S with TAMF_HIPCC_FLAGS=-DTAMF_CLIP_SAFE_WAIT).
 template <int N>
 TAMF_DEV void clip_wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
+#ifdef TAMF_CLIP_SAFE_WAIT
+  __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8));
+#else
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+#endif
 }
 
 // The K tiles this workgroup still has to request, across its tiles: round ri (tile clip_tile_of(ri)), K tile kti
