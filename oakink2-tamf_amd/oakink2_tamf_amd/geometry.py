@@ -119,13 +119,19 @@ def vertex_normals(verts: torch.Tensor, faces) -> torch.Tensor:
     v = _dev_f32(verts, dev)
     V = int(v.shape[-2])
     f_t = faces if isinstance(faces, torch.Tensor) else torch.as_tensor(faces)
-    key = (f_t.data_ptr() if f_t.is_cuda or f_t.is_cpu else 0, tuple(f_t.shape), V, str(dev), int(f_t.sum()), int((f_t.double() ** 2).sum()))
+    # one CSR per topology, keyed without touching the device (storage address, shape, in-place version counter): a batch that
+    # alternates rh / lh hands (two MANO face lists) keeps both; the keyed tensor is kept alive with its entry, so a recycled
+    # address cannot be mistaken for it.  A handful of entries at most (LRU of 8).
+    key = (f_t.data_ptr(), tuple(f_t.shape), f_t._version, str(f_t.device), str(f_t.dtype), V, str(dev))
     hit = _CSR_CACHE.get(key)
     if hit is None:
         off, ent = vertex_incidence_csr(f_t, V)
         hit = (torch.from_numpy(off).to(dev), torch.from_numpy(ent).to(dev), f_t)  # (f_t kept alive with its key)
-        _CSR_CACHE.clear()
-        _CSR_CACHE[key] = hit
+        while len(_CSR_CACHE) >= 8:
+            _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
+    else:
+        _CSR_CACHE.pop(key)  # re-inserted below: most recently used last
+    _CSR_CACHE[key] = hit
     n = v.numel() // (V * 3)
     out = torch.empty_like(v)
     with torch.cuda.device(dev):
