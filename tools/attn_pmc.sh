@@ -18,7 +18,7 @@ f = glob.glob("gpurun_out/apmc/**/*counter_collection.csv", recursive=True)
 if not f: print("pass $i: no counters ($grp)"); raise SystemExit
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(f[0])):
-    if "attn_kernel" not in r["Kernel_Name"]: continue
+    if "attn_" not in r["Kernel_Name"]: continue
     acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
     acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 print("pass $i", {k: list(v.values())[-1] for k, v in acc.items()})

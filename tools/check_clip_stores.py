@@ -63,15 +63,20 @@ def expected(op, nsub, ni, xsub, epi):
         sx = per(msx) * ni * cs
         static = (per(msx) + per(msy)) * ni * cs
     else:
+        hook = 0
         if epi == "EpiStoreF32":
             ch, cs = 4, 1
+        elif epi == "EpiSeqRows":  # fp32 row pieces + operand pieces; + the Y waves' prefix-row hook (one loop body: fp32 2 + operand)
+            ch = 4 if prec == 0 else 8
+            cs = ch // 4 + (2 if split else 1)
+            hook = 2 + (2 if (split or prec == 0) else 1)
         else:  # EpiBiasAct, EpiQK: operand output
             ch, cs = (4 if prec == 0 else 8), (2 if split else 1)
         nchunk = 4 * ni // ch
         sx = msx * nchunk * cs
         # three activation variants per wave role: GELU and SiLU run their row tiles in a loop (one row tile of stores in the text),
         # the plain one is unrolled (MS row tiles)
-        static = nchunk * cs * ((2 + msx) + (2 + msy))
+        static = nchunk * cs * ((2 + msx) + (2 + msy)) + hook
     return ph, sx, static
 
 
