@@ -421,6 +421,7 @@ struct EpiSeqRows {
   const float* temb;     // [n_t][d]
   const int* tcur;
   int has_t, S;
+  int t_off;             // steps since the counter was last written (position of this step inside its captured graph)
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -467,7 +468,7 @@ struct EpiSeqRows {
           int s;
           if (j < P) {
             s = j;
-            const float* src = (has_t && j == 0) ? temb + (long)tcur[b] * d : pstatic + ((long)b * (P - has_t) + (j - has_t)) * d;
+            const float* src = (has_t && j == 0) ? temb + (long)(tcur[b] - t_off) * d : pstatic + ((long)b * (P - has_t) + (j - has_t)) * d;
             g_load8(src + c, v);
           } else {
             s = S + (j - P);
@@ -600,26 +601,13 @@ struct EpiHead {
   const float* sigma;
   int n_steps;
   const LoopParams* __restrict__ lp;  // HEAD_DDPM only
-  // sampling loop only (else null): the step counter of every clip is decremented by the LAST workgroup of the launch to finish
-  // (one launch less per step).  Every workgroup reads tcur at the head of its epilogue and takes a ticket at its end, so the
-  // workgroup that draws the last ticket knows that all reads of this step are done; it also resets the ticket word.
-  unsigned* ticket;
-  int* tcur_rw;
-  int n_clips;
+  // Position of this step inside its captured graph: the device-side step counter `tcur` is written once per graph launch (by the
+  // one tiny kernel at the graph's end), step g of the graph works at t = tcur - g.  No per-step counter kernel and no atomics:
+  // a ticket scheme - the last workgroup of this launch to finish decrements the counter - cost the head launch 30 -> 37 us (208
+  // same-address atomics from 8 XCDs).
+  int t_off;
   template <int BM, int BN, int NT>
-  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid);
-    if (ticket) {
-      __syncthreads();  // every thread of this workgroup has read tcur
-      if (tid == 0) {
-        const unsigned old = atomicAdd(ticket, 1u);
-        if (old == gridDim.x - 1) {
-          for (int b = 0; b < n_clips; ++b) tcur_rw[b] -= 1;
-          __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-  }
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const { run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid); }
   template <int BM, int BN, int NT>
   TAMF_DEV void run_rows(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -650,7 +638,7 @@ struct EpiHead {
           if (c < F) x0_out[o] = nan_to_num(x_in[o] + (v[j] + bi[j]));
         }
       } else {
-        const int ti = tcur[0];
+        const int ti = tcur[0] - t_off;
         const float k1 = c1[ti], k2 = c2[ti], sg = sigma[ti];
         const float* noise = lp->noise;
         float* dump = lp->dump;

@@ -88,7 +88,6 @@ struct tamf_ctx {
         *objfeat = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
   int* tcur = nullptr;
-  unsigned* ticket = nullptr;  // workgroup ticket of the head kernel (EpiHead: the last one advances the step counter)
   unsigned char* side_dev = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
@@ -554,7 +553,6 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
   A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
   A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
-  A(dev_alloc(ctx, (void**)&ctx->ticket, 64, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
   A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
   if (rc) return bail(rc);
@@ -741,7 +739,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     EpiBiasAct<OpF32> e1{ctx->bt1, nullptr, 0, tmp, d, ACT_SILU};
     HIPCHK(ctx, gemm128<OpF32>(g1, e1, st));
     GemmArgs<OpF32> g2{tmp, d, (const float*)ctx->Wt2_f32.p, d, ctx->n_t, d, d, 0};
-    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, d, 0x7FFFFFFF, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+    EpiSeqRows<OpF32> e2{ctx->bt2, ctx->pe, 0, ctx->temb, nullptr, d, 0x7FFFFFFF, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     HIPCHK(ctx, gemm128<OpF32>(g2, e2, st));
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
@@ -867,7 +865,7 @@ static void launch_residual_ln(tamf_ctx* ctx, const float* gamma, const float* b
 }
 
 template <class Op>
-static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_in) {
+static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_in, int t_off = 0) {
   typedef typename Op::elem_t E;
   const int d = ctx->d, ff = ctx->ff, B = ctx->B, T = ctx->T, S = ctx->S, Sp = ctx->Sp, M = ctx->M, P = ctx->P;
   int nk = 0;
@@ -893,7 +891,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
     // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
-    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S};
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
@@ -987,7 +985,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   {
     // N = 128 is a single column tile: 64-row tiles (8 waves) double the workgroups that share the Philox-heavy epilogue
     GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)ctx->Wf.p, d, M, ctx->XN, d, 0};
-    HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head_in, st)));
+    EpiHead<Op> head = head_in;
+    head.t_off = t_off;
+    HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head, st)));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
   ctx->step_kernels = nk;
@@ -1088,14 +1088,13 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
                      (long long)clip_base);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
-  h.ticket = ctx->ticket;  // the head kernel's last workgroup decrements the step counter (no separate launch)
-  h.tcur_rw = ctx->tcur;
-  h.n_clips = B;
-  HIPCHK(ctx, hipMemsetAsync(ctx->ticket, 0, sizeof(unsigned), st));
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
                      (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {
-    for (int i = 0; i < N; ++i) TRY(enqueue_step<Op>(ctx, st, h));
+    for (int i = 0; i < N; ++i) {
+      TRY(enqueue_step<Op>(ctx, st, h));
+      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B, 1);
+    }
   } else {
     // G consecutive steps per graph (the largest divisor of N up to 16: 10 for N = 1000 -> 100 graph launches per loop);
     // the sequence is step-agnostic (device-side step counter) and seed-agnostic (LoopParams), so it is captured once per
@@ -1109,7 +1108,10 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
       TRY(retire_graph(ctx));
       HIPCHK(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
       int rc = 0;
-      for (int g = 0; g < G && rc == 0; ++g) rc = enqueue_step<Op>(ctx, ctx->cap_stream, h);
+      // step g of the graph works at t = counter - g (a kernel argument of its input-merge and head GEMMs); the counter itself
+      // moves once per graph launch
+      for (int g = 0; g < G && rc == 0; ++g) rc = enqueue_step<Op>(ctx, ctx->cap_stream, h, g);
+      hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, ctx->cap_stream, ctx->tcur, B, G);
       hipError_t ee = hipStreamEndCapture(ctx->cap_stream, &ctx->graph);
       if (rc) return rc;
       HIPCHK(ctx, ee);

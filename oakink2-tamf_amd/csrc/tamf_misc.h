@@ -133,6 +133,11 @@ __global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, i
   t = t < 0 ? 0 : (t >= n_t ? n_t - 1 : t);
   tcur[i] = (int)t;
 }
+// end of a captured graph of G steps: the step counter moves on by G
+__global__ void advance_t_kernel(int* tcur, int B, int G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tcur[i] -= G;
+}
 __global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float* dump, long stride, unsigned long long seed,
                                        long long clip_base) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
