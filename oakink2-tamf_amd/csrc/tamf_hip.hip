@@ -304,9 +304,12 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 #define TAMF_CLIP_XSUB_N4 6
 #endif
 template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? TAMF_CLIP_XSUB_N4 : TAMF_CLIP_XSUB_N2; };  // (5 : 8 spills the Y waves at 256 columns)
+#ifndef TAMF_CLIP_XSUB_PARTS  // X : Y row tiles of the 7-row-tile parts (A/B knob; FFN2 at B = 32: 2 : 5 46 us, 3 : 4 60 us, 4 : 3 slower still)
+#define TAMF_CLIP_XSUB_PARTS 2
+#endif
 template <class Op, int NI, class Epi, int NSUB = 13>
 struct ClipLaunch {
-  static constexpr int XSUB = ClipXsub<NI>::value;
+  static constexpr int XSUB = NSUB == 13 ? ClipXsub<NI>::value : TAMF_CLIP_XSUB_PARTS;
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   static hipError_t prepare() {
     static bool done[64] = {};
