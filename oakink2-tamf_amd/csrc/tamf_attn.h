@@ -307,11 +307,17 @@ struct AttnRes {
     const int n1 = nv1(Sp, nkb);
     return n1 >= 1 && (nkb - n1) * C::V_BYTES <= k_bytes(Sp);
   }
-  static int smem(int S, int Sp) { return k_bytes(Sp) + nv1(Sp, (S + 31) / 32) * C::V_BYTES; }
+  // (at least NKT key tiles of K rows: the straight-line score pass reads the rows of all NKT tiles - the ones past the clip hold
+  //  V^T bytes or nothing, and are masked - and must stay inside the workgroup's allocation)
+  static int smem(int S, int Sp) {
+    const int need = k_bytes(Sp) + nv1(Sp, (S + 31) / 32) * C::V_BYTES, rows = NKT * 16 * C::KROWB;
+    return need > rows ? need : rows;
+  }
 
-  static TAMF_DEV void issue_k(char* Ks, const char* kbase, int Sp, int d, int wave, int nw, int lane) {
-    const int np = (Sp * C::KROWB) >> 10;
-    for (int q = wave; q < np; q += nw) {
+  // K rows [r0, r1) (multiples of K_RPP): piece q covers rows [q K_RPP, (q + 1) K_RPP)
+  static TAMF_DEV void issue_k(char* Ks, const char* kbase, int r0, int r1, int d, int wave, int nw, int lane) {
+    const int q0 = r0 / BLK::K_RPP, np = r1 / BLK::K_RPP;
+    for (int q = q0 + wave; q < np; q += nw) {
       const int r = q * BLK::K_RPP + lane / BLK::KCH, pc = lane % BLK::KCH;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)r * (2 * d) * EB + BLK::kswz(pc, r) * 16),
                                        (__attribute__((address_space(3))) void*)(Ks + q * 1024), 16, 0, 0);
@@ -351,20 +357,27 @@ struct AttnRes {
   // (tile, group) steps ahead of the MFMAs that consume them (a wave alone would otherwise expose one LDS latency per step).
   // Ks / Vs never overlap: the __restrict__ qualifiers keep hipcc from waiting for the V^T requests before the first K
   // fragment read (as AttnBlock::run).
-  static TAMF_DEV void scores(const char* __restrict__ Ks, char* __restrict__ Vs, const char* vbase, int n1, int Skp, int wave,
-                              int nw, int lane, const int4 (&qf)[KG][2], f32x4 (&st)[NKT], int abl) {
+  // The FIRST call (T0 = 0) also requests what the later phases need - the second half of K into K2 and the V^T blocks [0, n1) into
+  // Vs - before its MFMAs; K1 (read here), K2 and Vs never overlap, which the __restrict__ qualifiers tell the compiler.
+  template <int T0, int T1>
+  static TAMF_DEV void scores(const char* __restrict__ Ks, char* __restrict__ K2, char* __restrict__ Vs, const char* kbase,
+                              const char* vbase, int k2r0, int k2r1, int d, int n1, int Skp, int wave, int nw, int lane,
+                              const int4 (&qf)[KG][2], f32x4 (&st)[NKT], int abl) {
     const int lr = lane & 15, g = lane >> 4;
-    if (!(abl & 1)) issue_v(Vs, vbase, 0, n1, Skp, wave, nw, lane);
-    constexpr int NF = NKT * KG, LA = 2;
+    if (T0 == 0 && !(abl & 1)) {
+      if (k2r1 > k2r0) issue_k(K2 - (long)k2r0 * C::KROWB, kbase, k2r0, k2r1, d, wave, nw, lane);
+      issue_v(Vs, vbase, 0, n1, Skp, wave, nw, lane);
+    }
+    constexpr int F0 = T0 * KG, NF = T1 * KG, LA = 2;
     const KOff ko = koff(lr, g);
     int4 kf[LA + 1][2];
 #pragma unroll
     for (int i = 0; i <= LA; ++i) kf[i][0] = kf[i][1] = qf[0][0];  // (defined contents for the no-read ablation)
 #pragma unroll
-    for (int i = 0; i < LA; ++i)
-      if (!(abl & 4)) kfrag(Ks, i, ko, kf[i]);
+    for (int i = F0; i < F0 + LA; ++i)
+      if (!(abl & 4)) kfrag(Ks, i, ko, kf[i % (LA + 1)]);
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
+    for (int i = F0; i < NF; ++i) {
       if (i + LA < NF && !(abl & 4)) kfrag(Ks, i + LA, ko, kf[(i + LA) % (LA + 1)]);
       __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks each read to its use: read, lgkmcnt(0), three MFMAs, ...)
       if (i % KG == 0) st[i / KG] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -478,12 +491,18 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
     }
   }
   const int abl = TAMF_ABL(aa.abl);
-  if (!(abl & 1)) R::issue_k(Ks, kbase, Sp, d, wave, nw, lane);
-  __syncthreads();  // K has landed (vmcnt(0) of every wave + barrier)
+  // K arrives in two halves: the key tiles [0, NKT / 2) first - every CU of the chip asks for its K at the same moment, and nothing
+  // can be multiplied before the first bytes are there - the rest (and V^T) under the score products of the first half
+  constexpr int TH = NKT / 2;
+  const int kh = TH * 16 < Sp ? TH * 16 : Sp;  // rows of the first half
+  if (!(abl & 1)) R::issue_k(Ks, kbase, 0, kh, d, wave, nw, lane);
+  __syncthreads();  // the first half of K has landed (vmcnt(0) of every wave + barrier)
 
   // ---- pass 1: scores of this wave's 16 queries against all keys; V^T blocks [0, n1) fly underneath
   f32x4 st[NKT];
-  R::scores(Ks, Vs, vbase, n1, aa.Skp, wave, nw, lane, qf, st, abl);
+  R::template scores<0, TH>(Ks, Ks + (long)kh * C::KROWB, Vs, kbase, vbase, kh, Sp, d, n1, aa.Skp, wave, nw, lane, qf, st, abl);
+  __syncthreads();  // the second half of K (and the V^T blocks) have landed
+  R::template scores<TH, NKT>(Ks, Vs, Vs, kbase, vbase, 0, 0, d, 0, aa.Skp, wave, nw, lane, qf, st, abl);
 
   // ---- exact softmax over the keys (per query = per lane column; the 4 lane groups hold disjoint keys)
 #pragma unroll
