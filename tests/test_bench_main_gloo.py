@@ -9,13 +9,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None):
+def _run(extra, env_extra=None, sampler="bench_stub:StubSampler"):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     if env_extra:
         env.update(env_extra)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--sampler", "bench_stub:StubSampler",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--sampler", sampler,
            "--arch", "arch_mdm", "--batch", "3", "--frames", "8", "--ddpm-steps", "4", "--steps", "2", "--warmup", "1"] + extra
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
@@ -31,6 +31,25 @@ def test_bench_self_spawns_two_ranks_and_gathers():
     assert j["config"]["rank_clip_ranges"] == [[0, 3], [3, 6]]
     assert j["config"]["global_clips"] == 6 and j["finite"] is True
     assert j["value"] > 0 and abs(j["value"] - 6 * 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+
+
+def test_a_dead_rank_ends_its_siblings():
+    """spawn_ranks watches its children: rank 1 exits with 7 before the process-group set-up, rank 0 - which would sit in the
+    rendezvous until its timeout - is terminated, and the launcher returns rank 1's code within seconds."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2"], sampler="bench_stub_dies:StubSampler")
+    assert r.returncode == 7, (r.returncode, r.stderr[-1500:])
+    assert time.monotonic() - t0 < 120
+    assert "terminating the other ranks" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no JSON line from a failed run
+
+
+def test_sampler_hook_needs_the_gloo_backend():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sampler", "bench_stub:StubSampler"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")])), timeout=120)
+    assert r.returncode != 0 and "needs --backend gloo" in r.stderr
 
 
 def test_bench_under_an_external_launcher_env():
