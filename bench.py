@@ -80,6 +80,13 @@ def hbm_traffic(dtype, kernel, B, T):
     return None, None
 
 
+def checks_ok(finite_by, range_flags, check):
+    """The line's `check_ok`: every reported dtype sampled finite values, no fp16 range flag was raised during the timed loops,
+    and every in-run oracle comparison is inside its per-dtype tolerance (NaN fails).  bench.py exits 3 when this is False."""
+    ok = all(finite_by.values()) and not any(range_flags.values())
+    return ok and all(e == e and e < CHECK_TOL[d] for d, e in check.items())
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota
     (the GPU box exposes 256 logical CPUs but grants a 16-CPU quota; oversubscribing it is 20x slower)."""
@@ -526,12 +533,11 @@ def main(argv=None, sampler_factory=None):
                                               "whole_path_frac_of_peak", "finite", "roofline")}
             line["fp32"]["what"] = ("the same workload in the reference's own arithmetic (v_mfma_f32_16x16x4_f32: exact fp32 products, "
                                     "fp32 accumulate), 1 GPU")
-        ok = all(finite_by.values()) and not any(range_flags.values())
         if check:
             line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
                              "what": f"one denoiser evaluation (t={N // 2}) of the first "
                              f"{min(args.check_clips, B)} clips of the bench batch vs oracle.denoiser_forward (fp32 torch-CPU restatement of the reference), outputs O(1)"}
-            ok = ok and all(e == e and e < CHECK_TOL[d] for d, e in check.items())
+        ok = checks_ok(finite_by, range_flags, check)
         if range_flags:
             line["f16_range_flag"] = range_flags  # True = an operand left the fp16 range during the timed loops (tamf_get_status_flags)
         line["finite_by_dtype"] = finite_by

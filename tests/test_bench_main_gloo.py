@@ -71,3 +71,16 @@ def test_bench_presets():
     a = bench.parse_args([])
     assert a.batch == 64 and a.frames == 196 and a.ddpm_steps == 1000 and a.gpus == 1
     assert bench.flops_per_clip_step(bench.ARCHS["arch_mdm_l"], 196) == 11127660544  # 11.128 GF per clip-step
+
+
+def test_check_ok_logic():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    good = dict(finite_by={"f16x3": True, "f32": True}, range_flags={"f16x3": False}, check={"f16x3": 4.4e-6, "f32": 2.2e-6, "bf16": 1e-2})
+    assert bench.checks_ok(**good)
+    assert not bench.checks_ok(**dict(good, finite_by={"f16x3": True, "f32": False}))
+    assert not bench.checks_ok(**dict(good, range_flags={"f16x3": True}))
+    assert not bench.checks_ok(**dict(good, check={"f16x3": 2e-5}))          # outside the 1e-5 gate
+    assert not bench.checks_ok(**dict(good, check={"bf16x3": float("nan")}))  # NaN never passes
+    assert bench.checks_ok(finite_by={"bf16": True}, range_flags={}, check={})
