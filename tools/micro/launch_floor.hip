@@ -29,6 +29,16 @@ __global__ void k_read(const float4* in, long n_per_wg, float* sink) {
   if (s == 12345.678f) sink[0] = s;
 }
 
+// every XCD reads the whole buffer of n float4 (workgroup b runs on XCD b % 8 and reads slice b / 8 of 32): what a weight matrix that
+// all eight L2s pull from the Infinity Cache costs, against the same number of fabric bytes of distinct data (k_read)
+__global__ void k_read_shared(const float4* in, long n, float* sink) {
+  const long per = n / 32;
+  const float4* p = in + (long)(blockIdx.x / 8) * per;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < per; i += blockDim.x) { const float4 v = p[i]; s += v.x + v.w; }
+  if (s == 12345.678f) sink[0] = s;
+}
+
 template <class F>
 static float per_launch_us(F launch, hipStream_t st, int iters, bool graph) {
   hipEvent_t e0, e1;
@@ -88,6 +98,12 @@ int main() {
         hipLaunchKernelGGL(k_read, dim3(256), dim3(512), 0, s, buf, n_per_wg, sink); }, st, iters, graph);
       printf("write %3d MB: plain %6.2f us (%.2f TB/s)  nt %6.2f us | write + read-back pair: plain %6.2f us  nt %6.2f us\n", mb, w, mb * 1.048576e6 / w / 1e6,
              wnt, wr, wrnt);
+    }
+    for (int mb : {4, 8, 13}) {  // W1 (4.2 MB), W1 + W2, all weights of a layer (12.6 MB) in the split modes
+      const long n = ((long)mb << 20) / 16;
+      const float sh = per_launch_us([&](hipStream_t s) { hipLaunchKernelGGL(k_read_shared, dim3(256), dim3(512), 0, s, buf, n, sink); }, st, iters, graph);
+      const float di = per_launch_us([&](hipStream_t s) { hipLaunchKernelGGL(k_read, dim3(256), dim3(512), 0, s, buf, n * 8 / 256, sink); }, st, iters, graph);
+      printf("read %2d MB by each of the 8 XCDs (%3d MB through the fabric): %6.2f us | %3d MB of distinct data: %6.2f us\n", mb, mb * 8, sh, mb * 8, di);
     }
     hipFree(buf); hipFree(sink);
   }
