@@ -564,7 +564,9 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
   if ((abl & 16) && inv != 12345.0f) return;
   constexpr int TPC = Op::EB == 4 ? 2 : 4;     // feature tiles per 128-byte row group (32 f32 or split elements / 64 bf16)
   constexpr int NCH = (NT16 + TPC - 1) / TPC, TPCE = NT16 < TPC ? NT16 : TPC;
-  constexpr int RS = 144;                      // slot row stride in bytes (128 + 16: two-way conflicts at worst)
+  // slot rows are 128 bytes (a wave's slot = 2 KiB <= the 16 K rows of its own queries, so the slots always fit the area they borrow),
+  // their 16-byte chunks XOR-swizzled by the row: the 8-byte column writes of the 16 lanes of a group are two-way conflicts at worst
+  constexpr int RS = 128;
   char* slot = (n1 < nkb ? Vs : Ks) + wave * (16 * RS);
   char* gout = (char*)aa.out + ((row_base + q0) * d + h * HD) * EB;
   const int srow = lane >> 3, spiece = lane & 7;
@@ -574,23 +576,27 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
     for (int tl = 0; tl < TPCE; ++tl) {
       const int nt = ch * TPC + tl;
       const float v0 = o[nt][0] * inv, v1 = o[nt][1] * inv, v2 = o[nt][2] * inv, v3 = o[nt][3] * inv;
+      if (q0 + lr >= Sp) continue;  // (rows past the clip are not stored - and with 128-byte K rows their slot rows would lie outside K)
       if constexpr (Op::PREC == 0) {
         // (written with the integer vector type the read-back below uses: a float4 store and an int4 load of the same bytes do not
-        //  alias under the type-based rules, and hipcc then moves the load ahead of the store)
-        *(int4*)(slot + lr * RS + (tl * 16 + 4 * g) * 4) = make_int4(as_i(v0), as_i(v1), as_i(v2), as_i(v3));
+        //  alias under the type-based rules)
+        const int c = 4 * tl + g;  // 16-byte chunk of elements 16 tl + 4 g ..
+        *(int4*)(slot + lr * RS + ((c ^ (lr & 7)) << 4)) = make_int4(as_i(v0), as_i(v1), as_i(v2), as_i(v3));
       } else {
         uint32_t h0, l0, h1, l1;
         Op::split2(v0, v1, h0, l0);
         Op::split2(v2, v3, h1, l1);
-        char* sp = slot + lr * RS + (tl * 16 + 4 * g) * 2;  // element c = 16 tl + 4 g of the group: hi at 2 c, lo 64 bytes further
-        *(int2*)sp = make_int2((int)h0, (int)h1);
-        if constexpr (Op::SPLIT) *(int2*)(sp + 64) = make_int2((int)l0, (int)l1);
+        // element e = 16 tl + 4 g of the group: hi at byte 2 e = chunk 2 tl + g / 2, half g & 1; lo 4 chunks (64 bytes) further
+        const int c = 2 * tl + (g >> 1);
+        char* sp = slot + lr * RS + 8 * (g & 1);
+        *(int2*)(sp + ((c ^ (lr & 7)) << 4)) = make_int2((int)h0, (int)h1);
+        if constexpr (Op::SPLIT) *(int2*)(sp + (((c + 4) ^ (lr & 7)) << 4)) = make_int2((int)l0, (int)l1);
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = i * 8 + srow;
-      const int4 w = *(const int4*)(slot + row * RS + spiece * 16);
+      const int4 w = *(const int4*)(slot + row * RS + ((spiece ^ (row & 7)) << 4));
       if (q0 + row < Sp && (NT16 >= TPC || spiece * 16 < NT16 * 16 * Op::EB))
         *(int4*)(gout + (long)row * d * EB + ch * 128 + spiece * 16) = w;
     }
