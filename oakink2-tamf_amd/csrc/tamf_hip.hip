@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -108,6 +109,7 @@ struct tamf_ctx {
 };
 
 static std::vector<tamf_ctx*> g_live_ctx;  // contexts of this process (tamf_set_gemm_tuning retires their captured graphs)
+static std::mutex g_live_mu;                // (contexts may be created / destroyed from different threads)
 
 static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -561,14 +563,20 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (rc) return bail(rc);
   if (hipEventCreateWithFlags(&ctx->graph_done, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, "hipEventCreate failed"));
-  g_live_ctx.push_back(ctx);
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.push_back(ctx);
+  }
   *out = ctx;
   return 0;
 }
 
 extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (!ctx) return;
-  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), ctx), g_live_ctx.end());
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), ctx), g_live_ctx.end());
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->graph_done) (void)hipEventDestroy(ctx->graph_done);
@@ -1564,8 +1572,10 @@ extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // context's graph is retired here: the next tamf_sample_loop re-captures with the new selection (same as tamf_denoise).
   const int sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
   const int rot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
-  if (sel != g_sel || rot != g_krot)
+  if (sel != g_sel || rot != g_krot) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
     for (tamf_ctx* c : g_live_ctx) (void)retire_graph(c);
+  }
   g_sel = sel;
   g_krot = rot;
   return 0;

@@ -89,8 +89,36 @@ def test_attention(hb, prec, B, S, H, hd):
     assert _rel(got, ref) < {"f32": 2e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
 
 
-def test_attention_online_softmax_rescale(hb):
-    """A late key block carrying the row maximum forces the running-max rescale path."""
+STREAMING = 0x200FFFFF  # tamf_set_gemm_tuning: selection bit 512 = the streaming (online-softmax) attention kernel
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,S,H,hd,tuning", [(1, 300, 2, 128, -1), (2, 260, 2, 64, -1),   # > 224 keys: only the streaming kernel serves them
+                                             (2, 201, 4, 128, STREAMING), (3, 21, 2, 64, STREAMING)])  # ... and it stays the A/B partner
+def test_attention_streaming_kernel(hb, prec, B, S, H, hd, tuning):
+    """The resident-K kernel covers S <= 224 (every shape of the launchers); longer sequences and selection bit 512 run the
+    round-2 streaming kernel, which must stay correct."""
+    g = torch.Generator().manual_seed(5)
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, generator=g)
+    q, k, v = qkv.double().split(d, dim=-1)
+    q = q.view(B, S, H, hd).transpose(1, 2)
+    k = k.view(B, S, H, hd).transpose(1, 2)
+    v = v.view(B, S, H, hd).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ v).transpose(1, 2).reshape(B, S, d)
+    hb.lib().tamf_set_gemm_tuning(tuning)
+    try:
+        got = hb.test_attention(prec, qkv.cuda(), H)
+    finally:
+        hb.lib().tamf_set_gemm_tuning(-1)
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < {"f32": 2e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
+
+
+@pytest.mark.parametrize("tuning", [-1, STREAMING])
+def test_attention_online_softmax_rescale(hb, tuning):
+    """A late key block carrying the row maximum: the streaming kernel's running-max rescale path (selection bit 512), and the
+    exact two-pass softmax of the resident-K kernel on the same input."""
     B, S, H, hd = 1, 201, 1, 128
     g = torch.Generator().manual_seed(4)
     qkv = torch.randn(B, S, 3 * hd, generator=g)
@@ -98,7 +126,11 @@ def test_attention_online_softmax_rescale(hb):
     q, k, v = qkv.double().split(hd, dim=-1)
     att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
     ref = att @ v
-    got = hb.test_attention("f32", qkv.cuda(), H)
+    hb.lib().tamf_set_gemm_tuning(tuning)
+    try:
+        got = hb.test_attention("f32", qkv.cuda(), H)
+    finally:
+        hb.lib().tamf_set_gemm_tuning(-1)
     assert _rel(got, ref) < 2e-5
 
 
