@@ -105,6 +105,13 @@ int main() {
       const float di = per_launch_us([&](hipStream_t s) { hipLaunchKernelGGL(k_read, dim3(256), dim3(512), 0, s, buf, n * 8 / 256, sink); }, st, iters, graph);
       printf("read %2d MB by each of the 8 XCDs (%3d MB through the fabric): %6.2f us | %3d MB of distinct data: %6.2f us\n", mb, mb * 8, sh, mb * 8, di);
     }
+    // is 6 TB/s a limit of the fabric or of 256 CUs x 24 GB/s?  the same 109 MB moved by 64 / 128 / 256 workgroups (one per CU)
+    for (int wgs : {64, 128, 256}) {
+      const long n_per_wg = (109l << 20) / 16 / wgs;
+      const float w = per_launch_us([&](hipStream_t s) { hipLaunchKernelGGL(k_write<0>, dim3(wgs), dim3(1024), 0, s, buf, n_per_wg); }, st, iters, graph);
+      const float r = per_launch_us([&](hipStream_t s) { hipLaunchKernelGGL(k_read, dim3(wgs), dim3(1024), 0, s, buf, n_per_wg, sink); }, st, iters, graph);
+      printf("109 MB by %3d workgroups x 1024 threads: write %6.2f us (%.2f TB/s)  read %6.2f us (%.2f TB/s)\n", wgs, w, 114.3 / w, r, 114.3 / r);
+    }
     hipFree(buf); hipFree(sink);
   }
   return 0;
