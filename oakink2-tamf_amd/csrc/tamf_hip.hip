@@ -226,12 +226,16 @@ template <class Op, int BM, int BN, class Epi, bool CAN_SPLIT = false>
 struct GemmLaunch {
   static constexpr int SMEM = GemmSmem<BM, BN>::BYTES;
   // wave grid: the 64-row LayerNorm tiles own a CU and run 8 waves (2 x 4), the 64 x 512 one 16 waves (2 x 8: four waves
-  // per SIMD cover each other's LDS / barrier latency, 36.6 -> 35.1 us for out-proj); the 128 x 128 tiles run 4 waves
-  // (2 x 2) with two workgroups per CU
+  // per SIMD cover each other's LDS / barrier latency, 36.6 -> 35.1 us for out-proj); the 128 x 128 tiles run 8 waves
+  // (4 x 2) with two workgroups per CU
+#ifndef TAMF_WGM128  // waves along M of the 128 x 128 tiles: 4 = 8 waves per workgroup (4 x 2), two workgroups per CU = 4 waves per SIMD.
+#define TAMF_WGM128 4  // Round 3, two builds alternating on one box: QKV 62.8 -> 60.7 us (f16x3), 31.5 -> 29.6 us (bf16) against the 2 x 2
+#endif                 // grid of rounds 1 - 2; the whole step -1 %: a workgroup left alone on its CU during its partner's epilogue keeps 2 waves per SIMD
   static constexpr int WGN = (BM <= 64) ? (BN == 512 ? 8 : 4) : 2;
+  static constexpr int WGM = (BM <= 64 || Op::PREC == 0) ? 2 : TAMF_WGM128;  // (f32: the 2 x 2 grid stays - input_merge.2 78 us against 91 us with 4 x 2)
   template <int SPLIT>
   static hipError_t prepare1() {
-    return hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, 2, WGN, Epi, SPLIT>,
+    return hipFuncSetAttribute((const void*)gemm_kernel<Op, BM, BN, WGM, WGN, Epi, SPLIT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t prepare() {  // kernel attributes are per device
@@ -278,12 +282,12 @@ struct GemmLaunch {
       gb.n_tiles = tiles;
       nblk = g_wg_slots;
     }
-    const dim3 grid(nblk), block(2 * WGN * 64);
+    const dim3 grid(nblk), block(WGM * WGN * 64);
     if constexpr (CAN_SPLIT) {
-      if (split == 4) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi, 4>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
-      if (split == 2) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi, 2>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
+      if (split == 4) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, WGM, WGN, Epi, 4>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
+      if (split == 2) { hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, WGM, WGN, Epi, 2>), grid, block, SMEM, st, gb, epi); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, 2, WGN, Epi, 1>), grid, block, SMEM, st, gb, epi);
+    hipLaunchKernelGGL((gemm_kernel<Op, BM, BN, WGM, WGN, Epi, 1>), grid, block, SMEM, st, gb, epi);
     return hipGetLastError();
   }
 };
