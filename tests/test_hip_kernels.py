@@ -89,6 +89,27 @@ def test_attention(hb, prec, B, S, H, hd):
     assert _rel(got, ref) < {"f32": 2e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,S,H,hd", [(2, 224, 2, 128), (2, 224, 2, 64), (1, 225, 2, 128), (2, 128, 2, 128), (2, 129, 2, 64), (3, 1, 2, 64),
+                                      (2, 8, 1, 128), (2, 16, 2, 64), (2, 17, 2, 128), (1, 113, 4, 64), (2, 97, 1, 128), (1, 208, 4, 128),
+                                      (5, 193, 3, 64)])
+def test_attention_size_boundaries(hb, prec, B, S, H, hd):
+    """The edges of the resident-K kernel's cases: 224 keys (its largest, 7 key blocks), 225 (first streaming size), 128 / 129 keys
+    (4 | 7 key-block instantiations), a single key, sizes one past a 16-row tile and sizes whose padded length is or is not a
+    multiple of 32 (the Vt block burst and the output slots differ), an odd head count (the XCD-affine pair order's remainder)."""
+    g = torch.Generator().manual_seed(7)
+    d = H * hd
+    qkv = torch.randn(B, S, 3 * d, generator=g)
+    q, k, v = qkv.double().split(d, dim=-1)
+    q = q.view(B, S, H, hd).transpose(1, 2)
+    k = k.view(B, S, H, hd).transpose(1, 2)
+    v = v.view(B, S, H, hd).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ v).transpose(1, 2).reshape(B, S, d)
+    got = hb.test_attention(prec, qkv.cuda(), H)
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < {"f32": 2e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
+
+
 STREAMING = 0x200FFFFF  # tamf_set_gemm_tuning: selection bit 512 = the streaming (online-softmax) attention kernel
 
 

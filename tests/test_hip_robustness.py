@@ -18,9 +18,10 @@ def _cond(B, T, tag, nobj=2):
     return O.det_cond(B, T, nobj=nobj, tag=tag, arch=O.ARCH_TINY)
 
 
-@pytest.mark.parametrize("B,T,nobj", [(1, 16, 1), (1, 3, 2), (5, 27, 4), (2, 59, 1), (3, 123, 2)])
+@pytest.mark.parametrize("B,T,nobj", [(1, 16, 1), (1, 3, 2), (5, 27, 4), (2, 59, 1), (3, 123, 2), (1, 1, 1), (2, 219, 1), (2, 220, 2), (1, 400, 1)])
 def test_odd_shapes_against_oracle(B, T, nobj):
-    """Sp = round_up(T + 5, 8) and Skp = round_up(T + 5, 32) padding paths, single clip, single frame tile, 4 objects."""
+    """Sp = round_up(T + 5, 8) and Skp = round_up(T + 5, 32) padding paths, single clip, single frame tile, 4 objects; a single frame;
+    T = 219 / 220 (224 keys: the largest resident-K attention case, 225: the first one of the streaming kernel) and a long clip."""
     from oracle import mdm_oracle as O
     from test_hip_forward import _set_cond
 
