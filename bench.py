@@ -16,7 +16,8 @@ all_gather of the sampled poses at the end of every loop, which is inside the ti
 
 value = (clips of all ranks) * T * K / (max-over-ranks wall time of the K timed loops), inputs resident in HBM.
 The line also carries, measured in the same run: `check` (max abs error of one denoiser evaluation against the oracle
-for every dtype reported), `roofline` (dominant kernel of the headline dtype, HIP events on the launch stream),
+for every dtype reported), `roofline` (dominant kernel of the headline dtype, HIP events on the launch stream; `peak` is the
+nominal figure, `mfma_sustained` what register-only MFMA loops reach on this very board under its power management),
 `other_dtypes` (the same workload in the other arithmetic modes, among them the reference's own fp32) and
 `cpu_baseline` (the oracle on the host cores).
 """
@@ -405,6 +406,21 @@ def main(argv=None, sampler_factory=None):
         got = sampler.denoise(xc.to(dev), tc.to(dev))[:nc].cpu()
         check[args.dtype] = float((got - ref).abs().max())
 
+    # what the matrix pipe of THIS board sustains by itself (register-only MFMA loops with random operands, 2 s per instruction
+    # kind, measured once): with real operand bits MI355X throttles well below the nominal peak - DESIGN.md section 6, "power"
+    sustained_cache = {}
+
+    def mfma_sustained(dtype):
+        kind = {"f32": "f32", "bf16": "bf16", "bf16x3": "bf16", "f16x3": "f16x3"}[dtype]
+        if kind not in sustained_cache:
+            from oakink2_tamf_amd.hip_backend import mfma_sustained_rate
+
+            tf, mhz = mfma_sustained_rate(kind, 2000, dev)
+            sustained_cache[kind] = {"value": tf, "unit": "TFLOP/s", "implied_sclk_mhz": mhz,
+                                     "what": "register-only " + {"f32": "v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x32_bf16", "f16x3": "v_mfma_f32_16x16x32_f16"}[kind]
+                                             + " loops with random operands on every SIMD of this GPU, 2 s, last two thirds timed (tamf_bench_mfma_rate)"}
+        return sustained_cache[kind]
+
     # dominant kernel, measured live with HIP events on the launch stream (rank 0)
     def roofline_of(smp, dtype, profile_out=None):
         agg = {}
@@ -429,6 +445,7 @@ def main(argv=None, sampler_factory=None):
         if profile_out:
             with open(profile_out, "w") as f:
                 json.dump({"dtype": dtype, "B": B, "T": T, "step_ms_eventsum": step_ms, "kernels": prof_rows}, f, indent=1)
+        sus = mfma_sustained(dtype)
         return {
             "bound": "mfma",
             "kernel": dom["kernel"],
@@ -438,6 +455,8 @@ def main(argv=None, sampler_factory=None):
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": dom["tflops"] / peak,
+            "mfma_sustained": sus,  # informational: `peak` above stays the nominal figure of MI355X_MICROARCH.md
+            "mfma_issue_frac_of_sustained": dom["tflops"] * MFMA_PER_PRODUCT[dtype] / sus["value"] if sus["value"] > 0 else None,
             "traffic": hbm_traffic(dtype, dom["kernel"], B, T)[0],
             "traffic_source": hbm_traffic(dtype, dom["kernel"], B, T)[1],
             "avg_launch_ms": dom["avg_ms"],

@@ -231,6 +231,12 @@ int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M
  * abl: ablation bits of csrc/tamf_attn.h AttnArgs::abl (honoured by -DTAMF_BENCH builds only). */
 int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t iters, int32_t abl, int32_t tuning,
                          float* ms_out, void* stream);
+/* What the matrix pipe of the current device sustains by itself: register-only MFMA loops (the mode's instruction: v_mfma_f32_16x16x4_f32,
+ * _16x16x32_bf16 or _16x16x32_f16) with random full-mantissa operands on every SIMD for about `millis` ms; the last two thirds are
+ * timed.  tflops_out: dense TFLOP/s (2 * 16 * 16 * K per MFMA); mhz_out (optional): the shader clock that rate implies at one MFMA per
+ * 16 cycles per SIMD (32 for the fp32 shape).  bench.py reports it beside the nominal peak: with real operand bits MI355X reaches its
+ * power management well below 2.5 PFLOP/s. */
+int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tflops_out, float* mhz_out, void* stream);
 /* Override the GEMM tuning / kernel-selection bits for every subsequent launch (-1 restores the per-kernel defaults); process-global;
  * retires the captured loop graphs of all live contexts so that the next tamf_sample_loop re-captures with the new selection.
  * The ablation bits (no loads / no MFMAs / no epilogue) only exist in -DTAMF_BENCH builds of the library. */

@@ -1470,6 +1470,50 @@ extern "C" int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int
   return rc;
 }
 
+extern "C" int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tflops_out, float* mhz_out, void* stream) {
+  if (precision < 0 || precision > TAMF_PREC_F16X3 || millis <= 0 || millis > 20000 || !tflops_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* sink = nullptr;
+  int cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return fail(nullptr, TAMF_ERR_HIP, "no device");
+  const int grid = 2 * cus, block = 512, iters = 4000;  // 2 workgroups x 8 waves per CU = 4 waves per SIMD; about 1 ms per launch
+  if (hipMalloc(&sink, (size_t)grid * block * sizeof(float)) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "hipMalloc failed");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  auto launch = [&]() {
+    if (precision == TAMF_PREC_F32) hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(grid), dim3(block), 0, st, sink, iters);
+    else if (precision == TAMF_PREC_F16X3) hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(grid), dim3(block), 0, st, sink, iters);
+    else hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(grid), dim3(block), 0, st, sink, iters);
+  };
+  // the first third of the time lets the power management settle, the rest is timed
+  float ms1 = 0.f, ms = 0.f;
+  launch();
+  hipEventRecord(e0, st);
+  launch();
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  hipEventElapsedTime(&ms1, e0, e1);
+  const int n_all = (int)(millis / (ms1 > 1e-3f ? ms1 : 1e-3f)) + 3, n_settle = n_all / 3, n = n_all - n_settle;
+  for (int i = 0; i < n_settle; ++i) launch();
+  hipEventRecord(e0, st);
+  for (int i = 0; i < n; ++i) launch();
+  hipEventRecord(e1, st);
+  hipError_t e = hipEventSynchronize(e1);
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(sink);
+  if (e != hipSuccess || !(ms > 0.f)) return fail(nullptr, TAMF_ERR_HIP, e != hipSuccess ? hipGetErrorString(e) : "no time measured");
+  const double mfmas = (double)n * grid * (block / 64) * (double)iters * 8;
+  const double flop_per_mfma = precision == TAMF_PREC_F32 ? 2.0 * 16 * 16 * 4 : 2.0 * 16 * 16 * 32;
+  *tflops_out = (float)(mfmas * flop_per_mfma / (ms * 1e-3) / 1e12);
+  // the clock this rate implies if the pipe issued one MFMA per 16 cycles (32 for the fp32 shape: 8 passes of 4 cycles): a LOWER bound of sclk
+  if (mhz_out) *mhz_out = (float)(mfmas / (cus * 4.0) * (precision == TAMF_PREC_F32 ? 32.0 : 16.0) / (ms * 1e-3) / 1e6);
+  return 0;
+}
+
 extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                                int32_t iters, float* ms_out, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");

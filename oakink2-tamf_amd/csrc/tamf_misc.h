@@ -138,6 +138,53 @@ __global__ void advance_t_kernel(int* tcur, int B, int G) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) tcur[i] -= G;
 }
+// What the matrix pipe sustains on THIS board with nothing else running (tamf_bench_mfma_rate): every wave issues 8 independent
+// MFMAs per iteration on register operands with full-mantissa random values - no LDS, no memory.  With real operand bits the chip
+// runs into its power management long before the issue rate of 16 cycles per MFMA at 2.4 GHz ("power").
+// MODE: 0 v_mfma_f32_16x16x4_f32, 1 v_mfma_f32_16x16x32_bf16, 2 v_mfma_f32_16x16x32_f16
+template <int MODE>
+__global__ __launch_bounds__(512) void mfma_rate_kernel(float* sink, int iters) {
+  const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+  auto rnd = [](unsigned x) {  // uniform in [-2, 2), all mantissa bits in use
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 22));
+  };
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == 0) {
+    float a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = rnd(id * 8 + i); b[i] = rnd(id * 8 + 4 + i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+    }
+  } else {
+    int4 a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+      uint32_t wa[4], wb[4];
+      for (int j = 0; j < 4; ++j) {
+        const float a0 = rnd(id * 64 + i * 8 + 2 * j), a1 = rnd(id * 64 + i * 8 + 2 * j + 1);
+        const float b0 = rnd(id * 64 + 32 + i * 8 + 2 * j), b1 = rnd(id * 64 + 32 + i * 8 + 2 * j + 1);
+        if constexpr (MODE == 1) { wa[j] = pack_bf16(a0, a1); wb[j] = pack_bf16(b0, b1); }
+        else { wa[j] = pack_f16(a0, a1); wb[j] = pack_f16(b0, b1); }
+      }
+      a[i] = make_int4((int)wa[0], (int)wa[1], (int)wa[2], (int)wa[3]);
+      b[i] = make_int4((int)wb[0], (int)wb[1], (int)wb[2], (int)wb[3]);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (MODE == 1) acc[i] = OpBF16::mfma1(a[i & 3], b[(i >> 1) & 3], acc[i]);
+        else acc[i] = OpF16X3::mfma1(a[i & 3], b[(i >> 1) & 3], acc[i]);
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (sum == 1234.5678f) sink[id] = sum;  // keeps the chains alive; never true in practice, and harmless if it is
+}
 __global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float* dump, long stride, unsigned long long seed,
                                        long long clip_base) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

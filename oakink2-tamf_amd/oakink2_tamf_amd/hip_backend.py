@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_uint64, c_void_p
-from typing import Dict, Mapping, Optional, Sequence
+from typing import Dict, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -71,6 +71,8 @@ def lib() -> ctypes.CDLL:
         L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
         L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
         L.tamf_test_philox.argtypes = [c_uint64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+        if hasattr(L, "tamf_bench_mfma_rate"):
+            L.tamf_bench_mfma_rate.argtypes = [c_int32, c_int32, POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]
         _bound = True
     return L
 
@@ -351,3 +353,13 @@ def test_philox(seed: int, clip_id_base: int, draw: int, B: int, F: int, T: int,
     _check(lib().tamf_test_philox(seed, clip_id_base, draw, B, F, T, c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
     torch.cuda.synchronize(dev)
     return out
+
+
+def mfma_sustained_rate(precision: str, millis: int = 1500, device=None) -> Tuple[float, float]:
+    """(dense TFLOP/s, implied shader MHz) of register-only MFMA loops in the mode's instruction on every SIMD of the device for
+    about `millis` ms: what the matrix pipe sustains on this board with real operand bits (include/tamf_hip.h tamf_bench_mfma_rate)."""
+    dev = require_gpu(device)
+    tf, mhz = ctypes.c_float(), ctypes.c_float()
+    with torch.cuda.device(dev):
+        _check(lib().tamf_bench_mfma_rate(PRECISIONS[precision], int(millis), ctypes.byref(tf), ctypes.byref(mhz), c_void_p(_stream_ptr(dev))))
+    return float(tf.value), float(mhz.value)

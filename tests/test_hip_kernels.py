@@ -162,3 +162,13 @@ def test_philox_matches_oracle(hb):
     ref = O.philox_normal(1234567890123, np.arange(40, 44), 3, 99, 64)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
     assert abs(got.mean()) < 0.03 and abs(got.std() - 1) < 0.03
+
+
+@pytest.mark.parametrize("prec,nominal", [("f32", 157.3), ("bf16", 2500.0), ("f16x3", 2500.0)])
+def test_mfma_sustained_rate(hb, prec, nominal):
+    """tamf_bench_mfma_rate: register-only MFMA loops on every SIMD; the rate is positive, below the nominal peak of the
+    instruction (MI355X_MICROARCH.md) and, for the 16-bit shapes with random operands, well above half of it."""
+    tf, mhz = hb.mfma_sustained_rate(prec, 300)
+    print(f"sustained {prec}: {tf:.0f} TFLOP/s, implied sclk >= {mhz:.0f} MHz")
+    assert 0.5 * nominal < tf < 1.02 * nominal
+    assert 800 < mhz < 2500
