@@ -152,6 +152,7 @@ def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, co
     start, stop = worker_range(n, worker_id, num_worker)
     bs = int(cfg["runtime"].get("batch_size", 64))
     T = int(cond["shape"].shape[1])
+    torch.manual_seed(known_seed)  # without a checkpoint every worker draws the SAME random weights (the split of the clips must not change a sample)
     model = InterationSegmentMDM(**mc, precision=precision, max_batch=min(bs, max(stop - start, 1)), max_frames=T).to(device)
     diffusion = create_gaussian_diffusion(diffusion_steps=diffusion_steps, noise_schedule="cosine")
     wpath = cfg["debug"].get("model_weight_filepath")

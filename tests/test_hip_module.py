@@ -241,6 +241,35 @@ def test_cli_synthetic_end_to_end(tmp_path, monkeypatch):
     assert "commit mode: setup ckpt" in (tmp_path / "common" / "sample" / "main" / "log.txt").read_text()
 
 
+def test_cli_two_workers_on_one_device_match_one_worker(tmp_path):
+    """runtime.num_worker 2 on one GPU (the reference runs up to two workers per device, launch/sample.py:118,274): two spawned
+    processes, each with its own context on cuda:0 and its own clip range; the device Philox noise is keyed by the global clip
+    id, so the files equal those of a single worker bit for bit.  The launcher runs as a child process (its workers are spawned
+    from a parent that has not touched the GPU, as in production)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    outs = {}
+    for nw in (1, 2):
+        wd = tmp_path / f"w{nw}"
+        wd.mkdir()
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]))
+        r = subprocess.run([sys.executable, "-m", "oakink2_tamf_amd.launch.sample", "--cfg", os.path.join(ROOT, "config", "arch_mdm.yml"),
+                            "--model.num_layers", "2", "--synthetic", "5,24", "--debug.sample_save_offset", "test/mw", "--runtime.device_id", "0",
+                            "--runtime.num_worker", str(nw), "--runtime.batch_size", "2", "--diffusion_steps", "6", "--commit"],
+                           cwd=wd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = wd / "common" / "sample" / "main" / "sample" / "test" / "mw"
+        files = sorted(os.listdir(d))
+        assert files == [f"{i:06d}.npy" for i in range(5)]
+        outs[nw] = [np.load(d / f) for f in files]
+    for a, b in zip(outs[1], outs[2]):
+        assert a.shape == (24, 99) and np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+
+
 def test_cli_loads_a_saved_checkpoint(tmp_path, monkeypatch):
     """--debug.model_weight_filepath: a torch.save'd state dict in the reference's format (flat keys, no clip_model.*,
     launch/sample.py:190-192 loads it with strict=False) goes through the launcher; the written samples equal the fused
