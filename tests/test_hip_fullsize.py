@@ -109,6 +109,27 @@ def test_clip_in_b64_equals_clip_alone(full, prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B", [1, 7, 65, 100, 128])
+def test_batches_beyond_and_beside_the_bench_shape(full, prec, B):
+    """More clips per GPU than the bench shape (65, 100, 128: more than one round of the persistent grids, tile counts that do not
+    divide by the CU count) and very small batches at T = 196: a context built for B clips evaluates them against the oracle
+    (clips repeat the B = 64 fixture cyclically) and every clip's bits equal those of the same clip in the B = 64 batch."""
+    idx = [i % B_FULL for i in range(B)]
+    cond = {k: (v[idx] if isinstance(v, torch.Tensor) else [v[i] for i in idx]) for k, v in full["cond"].items()}
+    x, t = full["x"][idx], full["t"][idx]
+    ctx = _make_ctx(full["arch"], full["sd"], max(B, B_FULL), T_FULL, prec)
+    _set_cond(ctx, cond)
+    out = ctx.denoise(x, t).cpu()
+    err = float((out - full["ref"][idx]).abs().max())
+    print(f"forward[{prec}] B={B} T=196: max|err| = {err:.3e}")
+    assert err < FWD_TOL[prec], (prec, B, err)
+    _set_cond(ctx, full["cond"])
+    base = ctx.denoise(full["x"], full["t"]).cpu()
+    assert torch.equal(out, base[idx]), (prec, B, float((out - base[idx]).abs().max()))
+    ctx.close()
+
+
 GEMM_TOL = {"f32": 1e-5, "f16x3": 2e-5, "bf16x3": 1e-4, "bf16": 2e-2}
 
 
