@@ -62,6 +62,20 @@ __global__ __launch_bounds__(512) void k_mfma(float* out, int iters, int data) {
       for (int i = 0; i < 8; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[MODE == 4 ? i : 0], b[MODE == 5 ? 0 : i], acc[i], 0, 0, 0);
     }
+  } else if (MODE == 7) {  // v_mfma_i32_16x16x64_i8: twice the multiply-adds per instruction of the 16-bit shapes (an Ozaki-style int8 slicing of fp32 would need 6 of them per product)
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    i4 a[4], b[4], c[8];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        a[i][j] = data == 0 ? 0 : (int)hash32(id * 64 + i * 4 + j); b[i][j] = data == 0 ? 0 : (int)hash32(id * 64 + 16 + i * 4 + j);
+      }
+    for (int i = 0; i < 8; ++i) c[i] = i4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i & 3], b[(i >> 1) & 3], c[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) acc[i][j] = (float)c[i][j];
   } else if (MODE == 3) {  // v_mfma_f32_32x32x16_f16: 4 independent 32 x 32 accumulators (64 registers), the same flops per instruction-cycle
     h8 a[4], b[4];
     for (int i = 0; i < 4; ++i)
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(512) void k_mfma(float* out, int iters, int data) {
 
 int main(int argc, char** argv) {
   const int secs = argc > 1 ? atoi(argv[1]) : 5;
-  const int ncase = 13;
+  const int ncase = 15;
   hipStream_t st;
   hipStreamCreate(&st);
   float* out;
@@ -103,6 +117,7 @@ int main(int argc, char** argv) {
       {0, 1, "f16 16x16x32 random", 16384.}, {0, 2, "f16 16x16x32 hi/lo pairs", 16384.}, {0, 0, "f16 16x16x32 zeros", 16384.},
       {1, 1, "bf16 16x16x32 random", 16384.}, {1, 2, "bf16 16x16x32 hi/lo pairs", 16384.}, {1, 0, "bf16 16x16x32 zeros", 16384.},
       {4, 1, "f16 16x16x32 no operand shared", 16384.}, {6, 1, "f16 16x16x32 A shared", 16384.}, {5, 1, "f16 16x16x32 A and B shared", 16384.},
+      {7, 1, "i8 16x16x64 random", 32768.}, {7, 0, "i8 16x16x64 zeros", 32768.},
       {3, 1, "f16 32x32x16 random", 32768.}, {3, 0, "f16 32x32x16 zeros", 32768.},
       {2, 1, "f32 16x16x4 random", 2048.},   {2, 0, "f32 16x16x4 zeros", 2048.}};
   const int iters = 20000, grid = 256 * 2, block = 512;  // 2 workgroups x 8 waves per CU = 4 waves per SIMD
@@ -113,6 +128,7 @@ int main(int argc, char** argv) {
       else if (cases[c].mode == 4) hipLaunchKernelGGL(k_mfma<4>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
       else if (cases[c].mode == 5) hipLaunchKernelGGL(k_mfma<5>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
       else if (cases[c].mode == 6) hipLaunchKernelGGL(k_mfma<6>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
+      else if (cases[c].mode == 7) hipLaunchKernelGGL(k_mfma<7>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
       else if (cases[c].mode == 3) hipLaunchKernelGGL(k_mfma<3>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
       else hipLaunchKernelGGL(k_mfma<2>, dim3(grid), dim3(block), 0, st, out, iters, cases[c].data);
     };
