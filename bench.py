@@ -62,12 +62,30 @@ def flops_per_clip_step(arch, T):
     return L * S * (8 * d * d + 4 * d * ff + 4 * S * d) + T * (4 * 99 * d + 6 * d * d) + 4 * d * d
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.h, *.hip, sorted by name): what a committed counter file is
+    stamped with (tools/collect_round_profiles.sh) and compared against - the GPU box has no .git, so a commit id cannot be
+    checked there, the sources can."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "oakink2-tamf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(dtype, kernel, B, T):
-    """(bytes per launch, source) of `kernel` from the committed PMC measurement of this exact workload
+    """(bytes per launch, source, stale) of `kernel` from the committed PMC measurement of this exact workload
     (profiles/rNN/hbm_traffic_<dtype>.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled
     per the gfx950 correction of MI355X_MICROARCH.md).  The counters cannot be collected inside a timed run (they need
     the profiler's own passes), so the value is NOT measured by this process: `source` names the file and the commit the
-    counters were taken at.  Newest round first; (None, None) when no measurement matches."""
+    counters were taken at; `stale` is True when the file's `csrc_sha16` stamp is missing or differs from the kernel sources of this
+    tree (the counters then describe OTHER kernels and the line says so).  Newest round first; (None, None, None) when no
+    measurement matches."""
     pdir = os.path.join(ROOT, "profiles")
     for rnd in sorted((d for d in os.listdir(pdir) if d.startswith("r")), reverse=True) if os.path.isdir(pdir) else []:
         try:
@@ -75,10 +93,11 @@ def hbm_traffic(dtype, kernel, B, T):
             with open(os.path.join(ROOT, rel)) as f:
                 m = json.load(f)
             if m.get("B") == B and m.get("T") == T and kernel in m["kernels"]:
-                return m["kernels"][kernel]["traffic_bytes_per_launch"], f"{rel}@{m.get('commit', 'unstamped')}"
+                return (m["kernels"][kernel]["traffic_bytes_per_launch"], f"{rel}@{m.get('commit', 'unstamped')}",
+                        m.get("csrc_sha16") != csrc_digest())
         except (OSError, ValueError, KeyError):
             continue
-    return None, None
+    return None, None, None
 
 
 def checks_ok(finite_by, range_flags, check):
@@ -381,10 +400,18 @@ def main(argv=None, sampler_factory=None):
     finite = bool(torch.isfinite(res).all().item())
     # range guard of the split-fp16 mode: sticky device flag raised by any operand store beyond +-65504 during the loops above
     range_flags = {}
+    my_flag = False
     if not stub and args.dtype == "f16x3":
-        range_flags[args.dtype] = bool(sampler.status_flags() & 1)
+        my_flag = bool(sampler.status_flags() & 1)
+        flag_any = my_flag
+        if world > 1:  # every rank's flag counts: MAX over ranks, like `elapsed`
+            tf_ = torch.tensor([1.0 if my_flag else 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tf_, op=dist.ReduceOp.MAX)
+            flag_any = bool(tf_.item() > 0)
+        range_flags[args.dtype] = flag_any
     # what every rank sampled, as seen by the collective (printed by rank 0)
-    rank_info = {"rank": rank, "clips": [clip0, clip0 + B], "device": str(dev)}
+    rank_info = {"rank": rank, "clips": [clip0, clip0 + B], "device": str(dev), "f16_range_flag": my_flag,
+                 "finite": bool(torch.isfinite(out).all().item())}
     if world > 1:
         infos = [None] * world
         dist.all_gather_object(infos, rank_info)
@@ -459,6 +486,7 @@ def main(argv=None, sampler_factory=None):
             "mfma_issue_frac_of_sustained": dom["tflops"] * MFMA_PER_PRODUCT[dtype] / sus["value"] if sus["value"] > 0 else None,
             "traffic": hbm_traffic(dtype, dom["kernel"], B, T)[0],
             "traffic_source": hbm_traffic(dtype, dom["kernel"], B, T)[1],
+            "traffic_stale": hbm_traffic(dtype, dom["kernel"], B, T)[2],  # True: the counter file was taken with other kernel sources
             "avg_launch_ms": dom["avg_ms"],
             "share_of_step": dom["share"],
             "attention": next(({"avg_launch_ms": r["avg_ms"], "tflops": r["tflops"], "frac": r["tflops"] / peak,
@@ -524,7 +552,9 @@ def main(argv=None, sampler_factory=None):
             "dtype": args.dtype,
             "data": "synthetic (random-init weights of the named arch, N(0,1) CLIP/object conditioning, device Philox noise)",
             "config": {
-                "workload": f"{args.arch} B={B}/GPU T={T} {N}-step DDPM ({CONFIGS[args.config]['label']}); step = one full reverse loop",
+                "workload": f"{args.arch} B={B}/GPU T={T} {N}-step DDPM ({CONFIGS[args.config]['label']}); step = one full reverse loop"
+                + ("; headline dtype f16x3 = split-fp16 operands, fp32-TOLERANCE mode (1e-5 vs the reference, checked in-run); the same workload in the "
+                   "reference's own fp32 arithmetic is under roofline.reference_arithmetic (and the top-level fp32 entry)" if args.dtype == "f16x3" else ""),
                 "preset": args.config,
                 "clips_per_gpu": B,
                 "frames": T,
@@ -533,6 +563,7 @@ def main(argv=None, sampler_factory=None):
                 "parallelism": f"clip-sharded x{world}, RCCL all_gather of results" if world > 1 else "single GPU",
                 "world_size_seen": world_seen,
                 "rank_clip_ranges": [i["clips"] for i in sorted(infos, key=lambda i: i["rank"])],
+                "ranks": sorted(infos, key=lambda i: i["rank"]),
                 "hipgraph": not args.no_graph,
                 "kernels_per_ddpm_step": sampler.kernels_per_step,
             },
@@ -552,6 +583,16 @@ def main(argv=None, sampler_factory=None):
                                               "whole_path_frac_of_peak", "finite", "roofline")}
             line["fp32"]["what"] = ("the same workload in the reference's own arithmetic (v_mfma_f32_16x16x4_f32: exact fp32 products, "
                                     "fp32 accumulate), 1 GPU")
+        # ... and INSIDE `roofline` (drivers that keep only the contract's top-level keys keep this one): the credited number at the
+        # reference's precision beside the fp32-tolerance headline
+        if roofline is not None and "fp32" in line:
+            fr = line["fp32"].get("roofline") or {}
+            roofline["reference_arithmetic"] = {
+                "dtype": "f32", "value": line["fp32"]["value"], "unit": "frames/s", "ms_per_ddpm_step": line["fp32"]["ms_per_ddpm_step"],
+                "timed_loops": line["fp32"].get("timed_loops"), "whole_path_frac_of_peak": line["fp32"].get("whole_path_frac_of_peak"),
+                "kernel": fr.get("kernel"), "achieved": fr.get("achieved"), "peak": fr.get("peak"), "frac": fr.get("frac"),
+                "attention_frac": (fr.get("attention") or {}).get("frac"),
+                "what": "the same workload in the reference's own arithmetic (exact fp32 MFMA products, fp32 accumulate)"}
         if check:
             line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
                              "what": f"one denoiser evaluation (t={N // 2}) of the first "

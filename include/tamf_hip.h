@@ -41,7 +41,7 @@ typedef enum tamf_status {
   TAMF_ERR_HIP = -3,       /* a HIP runtime call failed */
   TAMF_ERR_MISSING = -4,   /* a required checkpoint tensor was not loaded */
   TAMF_ERR_NOMEM = -5,
-  TAMF_ERR_RANGE = -6      /* a weight does not fit the operand format of the context's precision (f16x3: |w| > 65504) */
+  TAMF_ERR_RANGE = -6      /* a weight does not fit the operand format of the context's precision (f16x3: a non-finite weight) */
 } tamf_status;
 
 /* bits of tamf_get_status_flags */
@@ -92,7 +92,8 @@ const char* tamf_last_error(const tamf_ctx* ctx);
 int tamf_load_weight(tamf_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 /* Repack into kernel layouts (operand precision, fused input weights, timestep-embedding table for
  * t in [0, max_timesteps)).  Synchronises `stream`.  TAMF_ERR_MISSING names the first absent tensor;
- * TAMF_ERR_RANGE (f16x3 only) the first weight with max |w| > 65504 (see tamf_get_status_flags). */
+ * TAMF_ERR_RANGE (f16x3 only) the first tensor holding a non-finite weight (finite weights of any magnitude are stored scaled by
+ * a per-tensor power of two that the GEMM epilogue takes out again, exactly; see tamf_get_status_flags). */
 int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream);
 
 /* float64 tables of GaussianDiffusion.__init__ for the n_steps-step process; they are cast to float32
@@ -183,12 +184,14 @@ int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_dev, int32_
                        double* tri_workspace_dev, uint8_t* contains_out_dev, void* stream);
 
 /* Range guard of the split-fp16 mode.  The reference computes in fp32 (launch/sample.py:173); TAMF_PREC_F16X3 stores every
- * MFMA operand as two fp16 planes, so a weight or activation beyond +-65504 cannot be represented.  Weights are checked when
- * they are repacked (tamf_finalize_weights returns TAMF_ERR_RANGE and names the tensor); activations are checked by the kernels
- * that split them, which raise a sticky bit in a per-device status word.  This call synchronises `stream`, returns the bits
- * raised on the context's device since the last clear (by any context of this process on that device) in *flags and, with
- * clear != 0, resets them.  The Python module calls it after every forward / sampling loop and re-runs the call in
- * TAMF_PREC_F32 when the bit is set (oakink2_tamf_amd/model/interaction_segment_mdm.py). */
+ * MFMA operand as two fp16 planes, so an ACTIVATION beyond +-65504 cannot be represented (weights are pre-scaled per tensor by a
+ * power of two at tamf_finalize_weights - max |w| lands in [2^14, 2^15) - and only a non-finite weight is refused with
+ * TAMF_ERR_RANGE, naming the tensor).  Activations are checked by the kernels that split them, which raise a sticky bit in the
+ * status word of THEIR CONTEXT (a device allocation owned by the context; contexts on one device neither see nor clear each
+ * other's bits, and creating a context clears nothing).  This call synchronises `stream`, returns the bits raised by this
+ * context's launches since its last clear in *flags and, with clear != 0, resets them.  The Python module calls it after every
+ * forward / sampling loop and re-runs the call in TAMF_PREC_F32 when the bit is set
+ * (oakink2_tamf_amd/model/interaction_segment_mdm.py). */
 int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t clear, void* stream);
 
 /* Introspection for bench / profiles: number of kernels one denoiser step launches. */
@@ -237,7 +240,9 @@ int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int
  * 16 cycles per SIMD (32 for the fp32 shape).  bench.py reports it beside the nominal peak: with real operand bits MI355X reaches its
  * power management well below 2.5 PFLOP/s. */
 int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tflops_out, float* mhz_out, void* stream);
-/* Override the GEMM tuning / kernel-selection bits for every subsequent launch (-1 restores the per-kernel defaults); process-global;
+/* MEASUREMENT HOOK, not part of the drop-in surface (tools/ only; INTEGRATION.md does not bind it).  Overrides the GEMM tuning /
+ * kernel-selection bits for every subsequent launch (-1 restores the per-kernel defaults); process-global; serialised against
+ * every entry point that enqueues kernels (one process-wide lock), and
  * retires the captured loop graphs of all live contexts so that the next tamf_sample_loop re-captures with the new selection.
  * The ablation bits (no loads / no MFMAs / no epilogue) only exist in -DTAMF_BENCH builds of the library. */
 int tamf_set_gemm_tuning(int32_t krot);

@@ -137,16 +137,27 @@ TAMF_DEV int swz_chunk(int row) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sticky status word of this device (one per process and device; read and cleared by tamf_get_status_flags).
+// Sticky status word.  Every CONTEXT owns one (a 4-byte device allocation whose pointer travels in the epilogue structs and the
+// small kernels' arguments; read and cleared by tamf_get_status_flags of that context only), so two live contexts on one device
+// never see or clear each other's bits.  The process-wide word below serves only the context-less kernel test hooks.
 //   bit 0 (TAMF_STATUS_F16_RANGE): a value beyond the fp16 range (|v| > 65504, +-inf included; NaN is not counted) was
 //   stored as a split-fp16 operand - its hi part is then inf, its lo part NaN, and the products it enters differ from the
 //   reference's fp32 ones.  Raised by the kernels that split activations (Op::store_rc + Op::range_flag); weights are checked on the host
 //   (upload_operand).  Attention probabilities (<= 2^8 with the deferred rescale) are split without the check.
 // ---------------------------------------------------------------------------------------------
 __device__ unsigned g_tamf_status;
-TAMF_DEV void f16_range_flag(float absmax) {
-  if (absmax > 65504.0f) atomicOr(&g_tamf_status, 1u);
+TAMF_DEV void f16_range_flag(float absmax, unsigned* status) {
+  if (absmax > 65504.0f) atomicOr(status ? status : &g_tamf_status, 1u);
 }
+// What every epilogue carries besides its own fields (always its LAST member, so the positional initialisers stay short):
+//   wscale  2^-k of the weight tensor of this GEMM: f16x3 weights are stored pre-scaled by 2^k (upload_operand) so that their lo
+//           planes leave the fp16 subnormal range; the accumulator is multiplied back in the bias add, fma(acc, 2^-k, bias) - exact,
+//           a power of two - and 1.0 in every other mode (fma(acc, 1, b) = acc + b bit for bit)
+//   status  the context's status word (null: the process word, kernel test hooks)
+struct EpiCtl {
+  float wscale = 1.0f;
+  unsigned* status = nullptr;
+};
 
 // ---------------------------------------------------------------------------------------------
 // Operand traits.  Every operand matrix is row-major with K contiguous and is consumed in 128-byte row groups:
@@ -192,7 +203,7 @@ struct OpF32 {
   }
   template <int N>
   static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
-  static TAMF_DEV void range_flag(float) {}
+  static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = v; }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return base[idx]; }
 };
@@ -232,7 +243,7 @@ struct OpBF16 {
   }
   template <int N>
   static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
-  static TAMF_DEV void range_flag(float) {}
+  static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = (uint16_t)f2bf(v); }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return bf2f(base[idx]); }
 };
@@ -271,7 +282,7 @@ struct OpBF16X3 {
   }
   template <int N>
   static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
-  static TAMF_DEV void range_flag(float) {}
+  static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
     char* p = (char*)base + byte_off(idx);
@@ -328,7 +339,7 @@ struct OpF16X3 {
     for (int i = 0; i < N / 2; ++i) am = fmaxf(fmaxf(am, fabsf(v[2 * i])), fabsf(v[2 * i + 1]));
     store<N>(base, idx, v);
   }
-  static TAMF_DEV void range_flag(float am) { f16_range_flag(am); }
+  static TAMF_DEV void range_flag(float am, unsigned* status) { f16_range_flag(am, status); }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
     char* p = (char*)base + byte_off(idx);

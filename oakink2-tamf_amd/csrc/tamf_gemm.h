@@ -93,6 +93,7 @@ struct EpiBiasAct {
   typename OutOp::elem_t* out;
   int ldo;
   int act;
+  EpiCtl ctl;
   // Column constants of a thread (its 8 columns are the same for all its rows): loaded once per tile, ahead of the row
   // loops - a global load inside the row loop serialises the loop on L2 latency, and a load issued after stores waits for
   // them (vmcnt is in order), which is why the slab-wise epilogue of tamf_gemm_clip.h fetches these before its first slab
@@ -145,7 +146,7 @@ struct EpiBiasAct {
           float v[8];
           ct_load8(Ct, LDC, row, col, v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (v[j] + cc.bi[j]) + ra[i][j];
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], ctl.wscale, cc.bi[j]) + ra[i][j];
           act_store<8>(act, gr, gn, v, am);
         }
       }
@@ -158,9 +159,9 @@ struct EpiBiasAct {
         finish_act<8>(act, gr, gn, v, cc.bi, am);
       }
     }
-    OutOp::range_flag(am);
+    OutOp::range_flag(am, ctl.status);
   }
-  static TAMF_DEV void range_flag(float am) { OutOp::range_flag(am); }
+  TAMF_DEV void flag(float am) const { OutOp::range_flag(am, ctl.status); }
   // bias, row term, activation and operand store of N (4 or 8) consecutive columns gn .. of row gr: shared by the LDS-walking
   // form above and the register form of tamf_gemm_clip.h, so both produce the same bits.  `a` = this->act (the register form
   // passes it as a literal per branch, so that its unrolled row tiles carry one activation).  `am`: range accumulator of the
@@ -168,7 +169,7 @@ struct EpiBiasAct {
   template <int N>
   TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], float& am) const {
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] += bi[j];
+    for (int j = 0; j < N; ++j) v[j] = fmaf(v[j], ctl.wscale, bi[j]);
     if (rowadd) {
       float b[N];
       g_loadn<N>(rowadd + (long)gr * ld_rowadd + gn, b);
@@ -221,6 +222,7 @@ struct EpiQK {
   int d;
   float qscale;
   int act;  // (ACT_NONE; the register epilogue dispatches on it)
+  EpiCtl ctl;
   static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;
@@ -228,10 +230,10 @@ struct EpiQK {
   TAMF_DEV void finish_act(int, int gr, int gn, float (&v)[N], const float (&bi)[N], float& am) const {
     const float sc = (gn < d) ? qscale : 1.0f;
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = (v[j] + bi[j]) * sc;
+    for (int j = 0; j < N; ++j) v[j] = fmaf(v[j], ctl.wscale, bi[j]) * sc;
     Op::template store_rc<N>(qk, (long)gr * (2 * d) + gn, v, am);
   }
-  static TAMF_DEV void range_flag(float am) { Op::range_flag(am); }
+  TAMF_DEV void flag(float am) const { Op::range_flag(am, ctl.status); }
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const { g_loadn<N>(bias + gn, bi); }
 };
@@ -241,6 +243,7 @@ struct EpiVt {
   typename Op::elem_t* vt;
   int H, hd, Skp;
   int act;
+  EpiCtl ctl;
   static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
   static constexpr bool TRANSPOSED = true;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;  // (of one store_keys)
@@ -251,7 +254,7 @@ struct EpiVt {
     const int h = eg / hd, e = eg % hd;
     Op::template store_rc<N>(vt, ((long)(b * H + h) * hd + e) * Skp + pos0, v, am);
   }
-  static TAMF_DEV void range_flag(float am) { Op::range_flag(am); }
+  TAMF_DEV void flag(float am) const { Op::range_flag(am, ctl.status); }
 };
 
 // in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed
@@ -263,8 +266,10 @@ struct EpiQKV {
   typename Op::elem_t* vt;
   int d, H, hd, Sp, Skp;
   float qscale;
+  EpiCtl ctl;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+    const float ws = ctl.wscale;
     if (n0 < 2 * d) {
       constexpr int VPR = BN / 8, RSTEP = NT / VPR;
       static_assert(NT % VPR == 0, "column group must be fixed per thread");
@@ -286,12 +291,12 @@ struct EpiQKV {
           const int gr = m0 + tid / VPR + (r0 + i) * RSTEP;
           if (gr < M) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] + b[j]) * sc;
+            for (int j = 0; j < 8; ++j) v[i][j] = fmaf(v[i][j], ws, b[j]) * sc;
             Op::template store_rc<8>(qk, (long)gr * (2 * d) + gn, v[i], am);
           }
         }
       }
-      Op::range_flag(am);
+      Op::range_flag(am, ctl.status);
     } else if constexpr (Op::PREC == 0) {
       // f32: V^T rows keep the natural key order; one thread = 8 consecutive keys of one feature
       for (int it = tid; it < (BM / 8) * BN; it += NT) {
@@ -304,7 +309,7 @@ struct EpiQKV {
         const float bb = bias[n0 + col];
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Ct[(rg * 8 + j) * LDC + col] + bb;
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(Ct[(rg * 8 + j) * LDC + col], ws, bb);
         Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
       }
     } else {
@@ -352,10 +357,10 @@ struct EpiQKV {
             char* pp = (char*)vt + Op::byte_off(row_idx) + plane_off + q * 16;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = Ct[(r16 * 16 + 4 * q + j) * LDC + col] + bb;
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(Ct[(r16 * 16 + 4 * q + j) * LDC + col], ws, bb);
             if (pair) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 + j] = Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col] + bb;
+              for (int j = 0; j < 4; ++j) v[4 + j] = fmaf(Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col], ws, bb);
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[4 + j] = 0.f;
@@ -394,11 +399,11 @@ struct EpiQKV {
           const float bb = bias[n0 + col];
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = Ct[(row0 + j) * LDC + col] + bb;
+          for (int j = 0; j < 4; ++j) v[j] = fmaf(Ct[(row0 + j) * LDC + col], ws, bb);
           Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
         }
       }
-      Op::range_flag(am);
+      Op::range_flag(am, ctl.status);
     }
   }
 };
@@ -422,6 +427,7 @@ struct EpiSeqRows {
   const int* tcur;
   int has_t, S;
   int t_off;             // steps since the counter was last written (position of this step inside its captured graph)
+  EpiCtl ctl;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -453,7 +459,7 @@ struct EpiSeqRows {
         float v[8];
         ct_load8(Ct, LDC, row, col, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = nan_to_num(v[j] + bi[j]) + pv[i][j];
+        for (int j = 0; j < 8; ++j) v[j] = nan_to_num(fmaf(v[j], ctl.wscale, bi[j])) + pv[i][j];
         if (xout) g_store8(xout + orow * d + gn, v);
         if (xop) Op::template store_rc<8>(xop, orow * d + gn, v, am);
       }
@@ -481,7 +487,7 @@ struct EpiSeqRows {
         }
       }
     }
-    Op::range_flag(am);
+    Op::range_flag(am, ctl.status);
   }
 };
 
@@ -495,6 +501,7 @@ struct EpiLN {
   float* xout;  // [M][d] (may alias resid: every row is read and written by the same wave)
   typename Op::elem_t* xop;
   float eps;
+  EpiCtl ctl;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     (void)n0;
@@ -541,7 +548,7 @@ struct EpiLN {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
-        v[j] = (cp[j] + bi[j]) + rs[i][j];
+        v[j] = fmaf(cp[j], ctl.wscale, bi[j]) + rs[i][j];
         s += v[j];
       }
       float mean, var;
@@ -579,7 +586,7 @@ struct EpiLN {
       }
       Op::template store_rc<VPL>(xop, (long)gr * BN + c0, v, am);
     }
-    Op::range_flag(am);
+    Op::range_flag(am, ctl.status);
   }
 };
 
@@ -606,6 +613,7 @@ struct EpiHead {
   // a ticket scheme - the last workgroup of this launch to finish decrements the counter - cost the head launch 30 -> 37 us (208
   // same-address atomics from 8 XCDs).
   int t_off;
+  EpiCtl ctl;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const { run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid); }
   template <int BM, int BN, int NT>
@@ -628,14 +636,14 @@ struct EpiHead {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
-          if (c < F) x0_out[((long)b * F + c) * T + tau] = nan_to_num(v[j] + bi[j]);
+          if (c < F) x0_out[((long)b * F + c) * T + tau] = nan_to_num(fmaf(v[j], ctl.wscale, bi[j]));
         }
       } else if (mode == HEAD_RESIDUAL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
           const long o = ((long)b * T + tau) * F + c;
-          if (c < F) x0_out[o] = nan_to_num(x_in[o] + (v[j] + bi[j]));
+          if (c < F) x0_out[o] = nan_to_num(x_in[o] + fmaf(v[j], ctl.wscale, bi[j]));
         }
       } else {
         const int ti = tcur[0] - t_off;
@@ -670,7 +678,7 @@ struct EpiHead {
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
           if (c < F) {
-            const float x0 = nan_to_num(v[j] + bi[j]);
+            const float x0 = nan_to_num(fmaf(v[j], ctl.wscale, bi[j]));
             // mean = coef1*x0 + coef2*x_t ; sample = mean + [t!=0]*sigma*eps  (gaussian_diffusion.py:221-224,459)
             float r = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xt[j]));
             if (ti != 0) r = __fadd_rn(r, __fmul_rn(sg, ez[j]));
@@ -684,7 +692,7 @@ struct EpiHead {
         Op::template store_rc<8>(xs_op, srow + gn, xn, am);
       }
     }
-    Op::range_flag(am);
+    Op::range_flag(am, ctl.status);
   }
 };
 
@@ -694,6 +702,7 @@ struct EpiStoreF32 {
   float* out;
   int ldo;
   int act;
+  EpiCtl ctl;
   struct Cols {
     float bi[8];
     // a (free) register use that makes the compiler wait for the loads HERE, once: left to the first use inside a row loop,
@@ -729,11 +738,11 @@ struct EpiStoreF32 {
       finish_act<8>(act, gr, gn, v, cc.bi, am);
     }
   }
-  static TAMF_DEV void range_flag(float) {}  // (fp32 output: nothing to check)
+  TAMF_DEV void flag(float) const {}  // (fp32 output: nothing to check)
   template <int N>
   TAMF_DEV void finish_act(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], float&) const {
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] += bi[j];
+    for (int j = 0; j < N; ++j) v[j] = fmaf(v[j], ctl.wscale, bi[j]);
     if (a == ACT_SILU) {
 #pragma unroll
       for (int j = 0; j < N; ++j) v[j] = silu_exact(v[j]);

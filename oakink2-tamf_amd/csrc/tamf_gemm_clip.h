@@ -329,7 +329,7 @@ TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], 
   } else {
     clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, am);
   }
-  Epi::range_flag(am);
+  epi.flag(am);
 }
 
 // Register epilogue of the transposed form (EpiVt): lane (lr, g) holds, per row tile and column tile ni, feature
@@ -353,7 +353,7 @@ TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], in
       for (int ni = 0; ni < NI; ++ni) {
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? acc[mi][ni][j] + bb[ni] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? fmaf(acc[mi][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
         epi.template store_keys<4>(b, eg0 + 16 * ni, tok, v, am);
       }
     }
@@ -367,15 +367,15 @@ TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], in
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = tok0 < Sp ? acc[2 * u][ni][j] + bb[ni] : 0.f;
-          if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? acc[2 * u + 1][ni][j] + bb[ni] : 0.f;
+          v[j] = tok0 < Sp ? fmaf(acc[2 * u][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
+          if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? fmaf(acc[2 * u + 1][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
           else v[4 + j] = 0.f;
         }
         epi.template store_keys<8>(b, eg0 + 16 * ni, (s0 >> 1) * 32 + 8 * g, v, am);
       }
     }
   }
-  Epi::range_flag(am);
+  epi.flag(am);
 }
 
 // a (free) register use that makes the compiler wait for the column constants HERE, once, and not at their first use inside

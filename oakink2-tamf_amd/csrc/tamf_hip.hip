@@ -37,6 +37,7 @@ static std::string g_noctx_err;
 
 struct OperandBuf {
   void* p = nullptr;
+  float inv_scale = 1.0f;  // f16x3 weights are stored scaled by a power of two (upload_operand); this is its inverse, applied by the epilogue
 };
 
 struct LayerW {
@@ -89,6 +90,7 @@ struct tamf_ctx {
         *objfeat = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
   int* tcur = nullptr;
+  unsigned* status = nullptr;  // this context's sticky status word (tamf_device.h): written by its kernels only
   unsigned char* side_dev = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
@@ -110,6 +112,11 @@ struct tamf_ctx {
 
 static std::vector<tamf_ctx*> g_live_ctx;  // contexts of this process (tamf_set_gemm_tuning retires their captured graphs)
 static std::mutex g_live_mu;                // (contexts may be created / destroyed from different threads)
+// The tuning / selection words (g_krot, g_sel) are process-global and a captured graph has them baked in.  Every entry point that
+// enqueues kernels or touches a context's graph holds this lock for its (host-side, microseconds) duration, and so does
+// tamf_set_gemm_tuning: a thread inside loop_impl never sees a half-updated selection or a graph being destroyed under it.
+static std::recursive_mutex g_launch_mu;
+#define TAMF_LAUNCH_LOCK std::lock_guard<std::recursive_mutex> launch_lock_(g_launch_mu)
 
 static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -166,13 +173,26 @@ static inline float h_bf2f(uint16_t h) {
 static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what) {
   const size_t n = (size_t)N * ldk;
   if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
+  int wexp = 0;  // f16x3: the tensor is stored as w * 2^wexp
+  out->inv_scale = 1.0f;
   if (prec == TAMF_PREC_F16X3) {
-    // range guard of the split-fp16 format (weights; activations are checked on the device, tamf_device.h g_tamf_status)
+    // Power-of-two pre-scaling of the split-fp16 weights: max |w| lands in [2^14, 2^15), so that the lo planes of everything down to
+    // 2^-17 of the tensor's maximum are NORMAL fp16 numbers (22 significand bits; unscaled, PyTorch-default weights of ~0.04 had
+    // subnormal lo parts: an absolute 3e-8, i.e. ~19 bits) and a weight beyond the fp16 range is no reason to refuse a checkpoint.
+    // The product is scaled back exactly in the epilogue's bias add (EpiCtl::wscale).  Only a non-finite weight is refused.
+    // (activations are checked on the device: tamf_device.h, status word)
     float mx = 0.f;
-    for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::fmax(mx, std::fabs(w[i]));  // (fmax drops NaN)
-    if (mx > 65504.0f)
-      return fail(ctx, TAMF_ERR_RANGE, std::string("f16x3: weight ") + what + " has max |w| = " + std::to_string(mx) +
-                                           " > 65504 and cannot be stored as split-fp16 operands; use bf16x3 or f32");
+    for (size_t i = 0; i < (size_t)N * K; ++i) {
+      if (!std::isfinite(w[i]))
+        return fail(ctx, TAMF_ERR_RANGE, std::string("f16x3: weight ") + what + " holds a non-finite value and cannot be stored as split-fp16 operands; use bf16x3 or f32");
+      mx = std::fmax(mx, std::fabs(w[i]));
+    }
+    if (mx > 0.f) {
+      int e = 0;
+      (void)std::frexp(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+      wexp = std::min(120, std::max(-120, 15 - e));
+    }
+    out->inv_scale = std::ldexp(1.0f, -wexp);
   }
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
@@ -192,7 +212,8 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
       const size_t idx = (size_t)r * ldk + k;
       const size_t o = (idx >> 5) * 64 + (idx & 31);  // in uint16 units: 64 per 128-byte group
       if (prec == TAMF_PREC_F16X3) {
-        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        const float vs = std::ldexp(v, wexp);  // exact
+        const _Float16 hi = (_Float16)vs, lo = (_Float16)(vs - (float)hi);
         memcpy(&h[o], &hi, 2);
         memcpy(&h[o + 32], &lo, 2);
       } else {
@@ -562,6 +583,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
   A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
   A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
   A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
   if (rc) return bail(rc);
@@ -577,6 +599,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
 
 extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (!ctx) return;
+  TAMF_LAUNCH_LOCK;
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), ctx), g_live_ctx.end());
@@ -659,6 +682,7 @@ static int upload_f32(tamf_ctx* ctx, const std::string& name, float** p) {
 }
 
 extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
   if (ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights already finalised");
   if (max_timesteps <= 0 || max_timesteps > 5000) return fail(ctx, TAMF_ERR_INVALID, "max_timesteps must be in [1,5000]");
@@ -776,6 +800,7 @@ static int retire_graph(tamf_ctx* ctx) {
 }
 
 extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c1, const double* c2, const double* logvar) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx || !c1 || !c2 || !logvar || n_steps <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->h_c1.resize(n_steps);
@@ -809,6 +834,7 @@ extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c
 extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const float* text_emb_dev,
                              const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
                              const float* obj_traj_dev, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
   if (!ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights not finalised");
   if (B <= 0 || B > ctx->Bmax || T <= 0 || T > ctx->Tmax || nobj <= 0) return fail(ctx, TAMF_ERR_INVALID, "B/T/nobj out of range");
@@ -874,9 +900,9 @@ static void launch_residual_ln(tamf_ctx* ctx, const float* gamma, const float* b
   typedef typename Op::elem_t E;
   const int M = ctx->M, d = ctx->d, rows_per_blk = 4;
   dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
-  if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
-  else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
-  else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f);
+  if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f, ctx->status);
+  else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f, ctx->status);
+  else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_op.p, M, 1e-5f, ctx->status);
 }
 
 template <class Op>
@@ -898,7 +924,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   };
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
     GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->XK, (const E*)ctx->Wfused.p, ctx->XK, B * T, d, ctx->XK, 0};
-    EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, d, ACT_SILU};
+    EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, d, ACT_SILU, {ctx->Wfused.inv_scale, ctx->status}};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge0", BT * (2.0 * F * dd + 2.0 * dd * (ctx->arch.kind == TAMF_KIND_R ? 3 : 2) * dd +
                                     (ctx->arch.kind == TAMF_KIND_R ? 2.0 * ctx->arch.h2o_dim * dd : 0.0)));
@@ -906,7 +932,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
     // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
-    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off};
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_op.p, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off, {ctx->Wm2.inv_scale, ctx->status}};
     HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
@@ -920,18 +946,18 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // (f32: 174.5 against 190 us at B = 64; the 16-bit modes: 62.5 against 62 us, they stay on the 128 x 128 tiles; 128 = force)
       if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128 && ClipLaunch<Op, 2, EpiQK<Op>>::applies(B, Sp, 2 * d, d) &&
           ClipLaunch<Op, 2, EpiVt<Op>>::applies(B, Sp, d, d)) {
-        EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE};
+        EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}};
         if (ClipLaunch<Op, 4, EpiQK<Op>>::applies(B, Sp, 2 * d, d))  // the Q | K columns on 256-column tiles where they fill their rounds (f32, B = 64: 174.5 against 179 us)
           HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
         else
           HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
         const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
-        EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE};
+        EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}};
         mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
         mark("gemm_v", BS * 2.0 * dd * dd);
       } else {
-        EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale};
+        EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}};
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
         mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
       }
@@ -945,20 +971,20 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
       // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes keep the fused 64 x d tile (40 against 25 + 17 us)
       if ((Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32 && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, d)) {
-        EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE};
+        EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
         mark("gemm_outproj", BS * 2.0 * dd * dd);
         launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
         mark("outproj_residual_ln", 0.0);
       } else {
-        EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f};
+        EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f, {w.Wout.inv_scale, ctx->status}};
         HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
         mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
       }
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
-      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU};
+      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}};
       if ((g_sel & 32) && ClipLaunch<Op, 2, EpiBiasAct<Op>>::applies(B, Sp, ff, d))  // A/B: 128-column tiles (half the bytes per store burst)
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
       else if (!(g_sel & 8) && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
@@ -978,7 +1004,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
                          ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74);
       if ((Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
-        EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE};
+        EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE, {w.W2.inv_scale, ctx->status}};
         // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 row-tile parts of every clip
         // as tiles of their own fill the round (58 -> ~40 us; same bits)
         if (clip2 && ClipLaunch<Op, 2, EpiStoreF32, 7>::applies_parts(B, Sp, d, ff))
@@ -991,7 +1017,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         launch_residual_ln<Op>(ctx, w.g2, w.be2, st);
         mark("ffn2_residual_ln", 0.0);
       } else {
-        EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f};
+        EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f, {w.W2.inv_scale, ctx->status}};
         HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
         mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
       }
@@ -1027,6 +1053,7 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.sigma = ctx->sigma;
   h.n_steps = ctx->n_steps;
   h.lp = ctx->loop_params;
+  h.ctl = EpiCtl{ctx->Wf.inv_scale, ctx->status};
   return h;
 }
 
@@ -1035,7 +1062,7 @@ static int denoise_impl(tamf_ctx* ctx, const float* x, const int64_t* t_dev, flo
   typedef typename Op::elem_t E;
   const int B = ctx->B, T = ctx->T;
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x, ctx->xs, (E*)ctx->xs_op.p,
-                     B, ctx->F, T, ctx->XK, 0, 0ull, 0ll);
+                     B, ctx->F, T, ctx->XK, 0, 0ull, 0ll, ctx->status);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)t_dev, 0, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_X0);
   h.x0_out = out;
@@ -1045,6 +1072,7 @@ static int denoise_impl(tamf_ctx* ctx, const float* x, const int64_t* t_dev, flo
 }
 
 extern "C" int tamf_denoise(tamf_ctx* ctx, const float* x_dev, const int64_t* t_dev, float* x0_out_dev, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx || !x_dev || !t_dev || !x0_out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
   if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
   if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "tamf_denoise needs a G context");
@@ -1059,7 +1087,7 @@ static int refine_impl(tamf_ctx* ctx, const float* x_in, const float* h2o, float
   typedef typename Op::elem_t E;
   const int B = ctx->B, T = ctx->T;
   hipLaunchKernelGGL((refine_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, x_in, h2o, (E*)ctx->xs_op.p,
-                     B * T, ctx->F, ctx->arch.h2o_dim, ctx->XK);
+                     B * T, ctx->F, ctx->arch.h2o_dim, ctx->XK, ctx->status);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_RESIDUAL);
   h.x0_out = out;
   h.x_in = x_in;
@@ -1070,6 +1098,7 @@ static int refine_impl(tamf_ctx* ctx, const float* x_in, const float* h2o, float
 
 extern "C" int tamf_refine(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
                            void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx || !sample_pose_repr_dev || !h2o_dist_dev || !out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
   if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
   if (ctx->arch.kind != TAMF_KIND_R) return fail(ctx, TAMF_ERR_STATE, "tamf_refine needs an R context");
@@ -1100,7 +1129,7 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
   // draw 0 = x_T
   hipLaunchKernelGGL((state_in_kernel<Op>), grid1d((long)B * T * (ctx->XK / 8)), dim3(256), 0, st, noise, ctx->xs,
                      (E*)ctx->xs_op.p, B, ctx->F, T, ctx->XK, noise ? 0 : 1, (unsigned long long)seed,
-                     (long long)clip_base);
+                     (long long)clip_base, ctx->status);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
@@ -1146,6 +1175,7 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
 
 extern "C" int tamf_sample_loop(tamf_ctx* ctx, const float* noise_dev, uint64_t seed, int64_t clip_id_base, float* x0_out_dev,
                                 float* dump_dev, int32_t use_graph, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx || !x0_out_dev) return fail(ctx, TAMF_ERR_INVALID, "null argument");
   if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
   if (ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "schedule not set");
@@ -1161,13 +1191,11 @@ extern "C" int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t cle
   if (!ctx || !flags) return fail(ctx, TAMF_ERR_INVALID, "null argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+  // this context's own word (per-context since round 4: another context on the device neither sees nor clears it)
   unsigned v = 0;
-  HIPCHK(ctx, hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tamf_status), sizeof(v), 0, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(&v, ctx->status, sizeof(v), hipMemcpyDeviceToHost));
   *flags = v;
-  if (clear && v) {
-    const unsigned z = 0;
-    HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_tamf_status), &z, sizeof(z), 0, hipMemcpyHostToDevice));
-  }
+  if (clear && v) HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(v)));
   return 0;
 }
 
@@ -1190,6 +1218,7 @@ static int profile_impl(tamf_ctx* ctx, hipStream_t st) {
 
 extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host,
                                  void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (!ctx || !ms_host || !flops_host || !names_host || max_n <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
   if (!ctx->cond_set || ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "conditioning / schedule not set");
   if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "needs a G context");
@@ -1295,6 +1324,7 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
 
 extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
                               const float* bias_dev, int32_t act, float* c_dev, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (M <= 0 || N <= 0 || K <= 0 || N % 128) return fail(nullptr, TAMF_ERR_INVALID, "N must be a multiple of 128");
   hipStream_t st = (hipStream_t)stream;
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
@@ -1305,6 +1335,7 @@ extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K
 extern "C" int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
                                  const float* bias_dev, const float* resid_dev, const float* gamma_dev,
                                  const float* beta_dev, float* y_dev, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (M <= 0 || K <= 0 || !(N == 128 || N == 256 || N == 512)) return fail(nullptr, TAMF_ERR_INVALID, "N must be 128/256/512");
   hipStream_t st = (hipStream_t)stream;
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
@@ -1342,6 +1373,7 @@ static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* 
 
 extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
                                    float* out_dev, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (B <= 0 || S <= 0 || H <= 0 || !(hd == 64 || hd == 128)) return fail(nullptr, TAMF_ERR_INVALID, "bad attention shape");
   hipStream_t st = (hipStream_t)stream;
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
@@ -1459,6 +1491,7 @@ static int bench_attn_impl(int B, int S, int H, int hd, int iters, int abl, floa
 
 extern "C" int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t iters, int32_t abl,
                                     int32_t tuning, float* ms_out, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (B <= 0 || S <= 0 || H <= 0 || !(hd == 64 || hd == 128) || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   const int saved_rot = g_krot, saved_sel = g_sel;
@@ -1516,6 +1549,7 @@ extern "C" int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tf
 
 extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                                int32_t iters, float* ms_out, void* stream) {
+  TAMF_LAUNCH_LOCK;
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
   if (epi_kind == 1 && (N % 384 || M % 208)) return fail(nullptr, TAMF_ERR_INVALID, "qkv bench needs N = 3d, M multiple of 208");
   const int saved_rot = g_krot, saved_sel = g_sel;
@@ -1615,6 +1649,7 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
 }
 
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
+  TAMF_LAUNCH_LOCK;
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..30: kernel-selection overrides (g_sel).
   // The words are process-global and a captured loop graph has the selection of its capture time baked in, so every live
   // context's graph is retired here: the next tamf_sample_loop re-captures with the new selection (same as tamf_denoise).

@@ -7,7 +7,7 @@
 // draw0 != 0: ignore x and fill with Philox draw 0 (x_T of the throughput mode).
 template <class Op>
 __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__ xs, typename Op::elem_t* xs_op, int B, int F, int T, int XK, int philox, unsigned long long seed,
-                                long long clip_base) {
+                                long long clip_base, unsigned* status) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b*T + tau) * (XK/8) + cg
   const int CG = XK / 8;
   if (idx >= B * T * CG) return;
@@ -36,7 +36,7 @@ __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   float am = 0.f;
   Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);
-  Op::range_flag(am);
+  Op::range_flag(am, status);
 }
 
 // frame-major state -> (B, F, 1, T)
@@ -51,7 +51,7 @@ __global__ void state_out_kernel(const float* __restrict__ xs, float* __restrict
 // R trunk input operand: [B*T][XK] = [x_in (F) | h2o (Hd) | zero pad]
 template <class Op>
 __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __restrict__ h2o,
-                                 typename Op::elem_t* xs_op, int BT, int F, int Hd, int XK) {
+                                 typename Op::elem_t* xs_op, int BT, int F, int Hd, int XK, unsigned* status) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int CG = XK / 8;
   if (idx >= BT * CG) return;
@@ -67,7 +67,7 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
   }
   float am = 0.f;
   Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);
-  Op::range_flag(am);
+  Op::range_flag(am, status);
 }
 
 // y = LayerNorm(resid + c) * gamma + beta, one wave per row of D = 64 * VPL columns; writes fp32 + operand
@@ -75,7 +75,7 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
 template <class Op, int VPL>
 __global__ void residual_ln_kernel(const float* __restrict__ c, const float* resid, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* xout, typename Op::elem_t* xop, int M,
-                                   float eps) {
+                                   float eps, unsigned* status) {
   constexpr int D = 64 * VPL;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -121,7 +121,7 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
   }
   float am = 0.f;
   Op::template store_rc<VPL>(xop, (long)row * D + c0, v, am);
-  Op::range_flag(am);
+  Op::range_flag(am, status);
 }
 
 // current timestep of every clip; clamped to the rows of the timestep-embedding table (the host wrapper raises on an

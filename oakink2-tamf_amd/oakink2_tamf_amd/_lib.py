@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(_HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(_HERE, "lib", "libtamf_hip.so")
-SOURCES = ["tamf_hip.hip", "tamf_device.h", "tamf_gemm.h", "tamf_gemm_clip.h", "tamf_attn.h", "tamf_misc.h", "tamf_geom.h"]
+SOURCES = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] if os.path.isdir(CSRC) else []
 
 _lock = threading.Lock()
 _lib = None
@@ -51,16 +51,47 @@ def build(force: bool = False, verbose: bool = False) -> str:
         lock.close()
 
 
-def _build_locked(hipcc: str, verbose: bool) -> str:
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", tmp, os.path.join(CSRC, "tamf_hip.hip")] + os.environ.get("TAMF_HIPCC_FLAGS", "").split()
-    res = subprocess.run(cmd, capture_output=True, text=True)
+def _compile(hipcc: str, workdir: str, extra):
+    """One hipcc run in `workdir` with -save-temps=obj: the library AND the device assembly of the same compile.
+    The product build takes no flags from the environment (tools/ab_build.sh builds the -DTAMF_BENCH / -DTAMF_TIMELINE copies
+    for measurements under other file names)."""
+    out = os.path.join(workdir, "libtamf_hip.so")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-save-temps=obj",
+           "-o", out, os.path.join(CSRC, "tamf_hip.hip")] + list(extra)
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
     if res.returncode != 0:
         raise TamfBuildError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB_PATH)
+    asm = [f for f in os.listdir(workdir) if f.endswith("gfx950.s")]
+    return out, (os.path.join(workdir, asm[0]) if asm else None)
+
+
+def _build_locked(hipcc: str, verbose: bool) -> str:
+    import tempfile
+
+    from . import _isa_check
+
+    with tempfile.TemporaryDirectory(prefix="tamf_build_", dir=os.path.dirname(LIB_PATH)) as wd:
+        out, asm = _compile(hipcc, wd, [])
+        # the clip-tile GEMM's counted waits assume one global_store per source-level store: verified on the assembly of THIS
+        # compile (whatever hipcc the site has); on a mismatch the library is rebuilt with every counted wait as vmcnt(0)
+        safe = False
+        try:
+            if asm is None:
+                raise _isa_check.IsaMismatch("hipcc left no device assembly to check")
+            n = _isa_check.check(asm)
+            if verbose:
+                print(f"ISA check: all {n} clip_gemm_kernel instantiations match the counted waits")
+        except _isa_check.IsaMismatch as e:
+            import warnings
+
+            warnings.warn(f"libtamf_hip: {e}\nrebuilding with -DTAMF_CLIP_SAFE_WAIT (counted waits -> vmcnt(0))")
+            for f in os.listdir(wd):
+                os.remove(os.path.join(wd, f))
+            out, _ = _compile(hipcc, wd, ["-DTAMF_CLIP_SAFE_WAIT"])
+            safe = True
+        os.replace(out, LIB_PATH)
     if verbose:
-        print("built", LIB_PATH)
+        print("built", LIB_PATH, "(safe waits)" if safe else "")
     return LIB_PATH
 
 

@@ -118,11 +118,20 @@ def vertex_normals(verts: torch.Tensor, faces) -> torch.Tensor:
     dev = require_gpu(verts.device)
     v = _dev_f32(verts, dev)
     V = int(v.shape[-2])
-    f_t = faces if isinstance(faces, torch.Tensor) else torch.as_tensor(faces)
+    is_t = isinstance(faces, torch.Tensor)
+    f_t = faces if is_t else torch.as_tensor(faces)
     # one CSR per topology, keyed without touching the device (storage address, shape, in-place version counter): a batch that
     # alternates rh / lh hands (two MANO face lists) keeps both; the keyed tensor is kept alive with its entry, so a recycled
     # address cannot be mistaken for it.  A handful of entries at most (LRU of 8).
-    key = (f_t.data_ptr(), tuple(f_t.shape), f_t._version, str(f_t.device), str(f_t.dtype), V, str(dev))
+    # A numpy array / list has no version counter (torch.as_tensor gives a fresh tensor with _version 0 every call, and an in-place
+    # edit of the array would go unseen): such faces are keyed by CONTENT.
+    if is_t:
+        key = (f_t.data_ptr(), tuple(f_t.shape), f_t._version, str(f_t.device), str(f_t.dtype), V, str(dev))
+    else:
+        import hashlib
+
+        fc = f_t.contiguous()
+        key = ("content", hashlib.sha1(fc.numpy().tobytes()).hexdigest(), tuple(fc.shape), str(fc.dtype), V, str(dev))
     hit = _CSR_CACHE.get(key)
     if hit is None:
         off, ent = vertex_incidence_csr(f_t, V)

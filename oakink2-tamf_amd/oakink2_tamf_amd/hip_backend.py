@@ -19,11 +19,12 @@ class TamfError(RuntimeError):
 
 
 class TamfRangeError(TamfError):
-    """A weight (at load) or an activation (status flag) does not fit the split-fp16 operand format of "f16x3"."""
+    """A non-finite weight (at load) or an activation beyond +-65504 (status flag) does not fit the split-fp16 operand format of "f16x3"."""
 
 
 STATUS_F16_RANGE = 1
-DEFAULT_PRECISION = "f16x3"  # fp32-equivalent (22 significand bits, meets the 1e-5 gate), range-guarded; DESIGN.md section 2
+DEFAULT_PRECISION = "f16x3"  # fp32-equivalent at the stated 1e-5 tolerance (22 significand bits for values >= 2^-3 of fp16's normal range - weights
+# are pre-scaled into it - and an absolute 3e-8 operand error below |v| = 0.12 for activations), range-guarded; DESIGN.md section 2
 
 
 class _Arch(ctypes.Structure):
@@ -263,8 +264,9 @@ class TamfContext:
         return (out, dmp) if dump else out
 
     def status_flags(self, clear: bool = True) -> int:
-        """Sticky status bits of this context's device (STATUS_F16_RANGE: an activation beyond +-65504 was stored as a
-        split-fp16 operand since the last clear).  Synchronises the current stream."""
+        """Sticky status bits of THIS context (STATUS_F16_RANGE: one of its launches stored an activation beyond +-65504 as a
+        split-fp16 operand since its last clear; other contexts on the device have their own words).  Synchronises the
+        current stream."""
         v = ctypes.c_uint32(0)
         with torch.cuda.device(self.device):
             _check(lib().tamf_get_status_flags(self._h, ctypes.byref(v), 1 if clear else 0, c_void_p(_stream_ptr(self.device))),

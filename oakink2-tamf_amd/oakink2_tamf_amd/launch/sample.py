@@ -196,7 +196,9 @@ def main(argv=None):
     import torch
     import torch.multiprocessing as mp
 
-    n_dev = max(torch.cuda.device_count(), 1)  # (on this ROCm image counting devices does not initialise the GPU in this process)
+    # (device_count() may call hipGetDeviceCount in THIS process; harmless here: the workers below are fresh `spawn` processes, this
+    #  parent is never re-executed, and with one worker the parent is the worker)
+    n_dev = max(torch.cuda.device_count(), 1)
     want = cfg["runtime"].get("device_id")
     device_ids = ([d for d in want if d < n_dev] or [0]) if want else list(range(n_dev))
     n_clips = int(cond["shape"].shape[0])

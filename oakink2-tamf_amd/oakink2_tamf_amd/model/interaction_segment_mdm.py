@@ -14,8 +14,9 @@ Differences from the reference, all deliberate:
   * step-invariant conditioning (prefix tokens 1..4, object half of input_merge.0) is computed once per batch dict;
   * eval only (dropout is identity in the reference's eval mode; autograd is not supported);
   * arithmetic: `precision` (default "f16x3", hip_backend.DEFAULT_PRECISION - the same default in the CLIs and bench.py)
-    selects the MFMA operand format.  "f16x3" (split fp16, fp32-equivalent at the stated 1e-5 tolerance) cannot hold values
-    beyond +-65504; `range_check` says what happens when a weight or an activation leaves that range:
+    selects the MFMA operand format.  "f16x3" (split fp16, fp32-equivalent at the stated 1e-5 tolerance) cannot hold ACTIVATIONS
+    beyond +-65504 (weights are pre-scaled per tensor by a power of two and fit whatever their magnitude; only a non-finite
+    weight is refused); `range_check` says what happens when an activation leaves that range or a weight is non-finite:
     "fallback" (default) - the call is repeated in "f32" (the reference's own arithmetic) on a new library context and the
     module stays there; "raise" - hip_backend.TamfRangeError; "off" - no check (no stream synchronisation per call);
   * train()/eval() return self (the reference's override returns None, :176-178).
@@ -138,9 +139,7 @@ class _HipDenoiserBase(nn.Module):
                         raise
                     _logger.warning("%s - falling back to f32 arithmetic", e)
                     self.active_precision = "f32"
-            self._ctx = ctx
-            if self._guarded():
-                ctx.status_flags(clear=True)  # bits left by an earlier context of this process on the device
+            self._ctx = ctx  # (its status word is its own and starts clear: nothing to reset, nobody else's evidence to erase)
             self._ctx_dirty = False
             self._cond_key = None
             self._sched_key = None

@@ -218,3 +218,23 @@ def test_hip_vertex_normals():
     assert got.shape == (2, 196, 778, 3)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
     assert (got[:, :, 642:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_hip_vertex_normals_numpy_faces_are_keyed_by_content():
+    """a numpy face array edited in place must not hit the CSR cached for its old content (torch.as_tensor of a numpy
+    array always has _version 0), and equal lists hit the cache."""
+    from oakink2_tamf_amd import geometry
+    from oracle import fixtures as FX
+
+    sv, sf = FX.icosphere(1)
+    v = torch.from_numpy(sv.astype(np.float32)).cuda()
+    faces = np.array(sf, dtype=np.int64)
+    n1 = geometry.vertex_normals(v, faces).cpu().numpy()
+    np.testing.assert_allclose(n1, G.vertex_normals(sv.astype(np.float32), faces), rtol=0, atol=2e-7)
+    faces[:, [1, 2]] = faces[:, [2, 1]]  # flip every triangle IN PLACE: the normals must flip too
+    n2 = geometry.vertex_normals(v, faces).cpu().numpy()
+    np.testing.assert_allclose(n2, -n1, rtol=0, atol=2e-7)
+    n_before = len(geometry._CSR_CACHE)
+    geometry.vertex_normals(v, faces.tolist())  # same content as a list: same key
+    assert len(geometry._CSR_CACHE) == n_before

@@ -160,7 +160,7 @@ def test_loop_1000_real_architectures(name, arch_name, B, T, prec):
     shape = (B, 99, 1, T)
     ctx = _make_ctx(arch, sd, B, T, prec, n_steps=1000)
     _set_cond(ctx, cond)
-    ctx.status_flags()  # clear: the word is per device and sticky (the non-finite fixtures of earlier tests raise it)
+    assert ctx.status_flags(clear=False) == 0  # a context's status word is its own and starts clear
     out, dump = ctx.sample_loop(noise=_draws_1000(name, shape), dump=True)
     errs = {}
     for s_ in fix["dump_steps"]:

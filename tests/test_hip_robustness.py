@@ -199,7 +199,7 @@ def test_f16x3_activation_overflow_raises_the_status_flag():
     # in range: no flag, in any call
     ctx = _ctx(arch, sd, 2, 16, "f16x3")
     _set_cond(ctx, cond)
-    ctx.status_flags()  # clear what earlier tests may have left on the device
+    assert ctx.status_flags(clear=False) == 0  # the word belongs to this context and starts clear
     ctx.denoise(x, t)
     ctx.sample_loop(noise=None, seed=1)
     assert ctx.status_flags() == 0
@@ -226,29 +226,89 @@ def test_f16x3_activation_overflow_raises_the_status_flag():
     ctx.close()
 
 
-def test_f16x3_weight_beyond_range_is_refused_at_load():
+def test_f16x3_weights_of_any_finite_magnitude_load_and_only_non_finite_ones_are_refused():
+    """Round 4: split-fp16 weights are stored scaled by a per-tensor power of two (max |w| in [2^14, 2^15)) that the epilogue
+    takes out again, so a weight beyond 65504 - or a whole tensor of tiny weights - is no reason to refuse a checkpoint; the
+    result stays at the fp32 gate.  Only a non-finite weight is TAMF_ERR_RANGE."""
     from oakink2_tamf_amd.hip_backend import TamfContext, TamfRangeError
     from oracle import mdm_oracle as O
-    from test_hip_forward import _arch_dict
+    from test_hip_forward import _arch_dict, _set_cond
 
     arch = O.ARCH_TINY
-    sd = {k: v.clone() for k, v in O.det_state_dict(arch, tag="rob/w").items()}
+    base = O.det_state_dict(arch, tag="rob/w")
+    cond = _cond(2, 16, "range")
+    x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([10, 700])
+    # (a) one huge weight in linear2 (its product goes to the fp32 LayerNorm, never into an fp16 operand)
+    sd = {k: v.clone() for k, v in base.items()}
     sd["seqTransEncoder.layers.1.linear2.weight"][3, 7] = 7.0e4
-    ctx = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3")
-    with pytest.raises(TamfRangeError, match="layers.1.linear2.weight"):
-        ctx.load_state_dict(sd)
-    ctx.close()
-    for prec in ("bf16x3", "f32"):  # the other formats have fp32's exponent range
+    # (b) every encoder weight scaled down by 2^-12 with the LayerNorm after it undoing nothing: products of ~1e-5 - unscaled, the
+    #     lo planes of such weights would be fp16 subnormals or zero (~8 significand bits left)
+    sd_small = {k: v.clone() for k, v in base.items()}
+    for k in sd_small:
+        if k.endswith("linear1.weight") or k.endswith("in_proj_weight"):
+            sd_small[k] *= 2.0 ** -12
+    for tag, w in (("huge", sd), ("tiny", sd_small)):
+        ref = O.denoiser_forward(w, arch, x, t, cond)
+        assert torch.isfinite(ref).all()
+        ctx = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3")
+        ctx.load_state_dict(w)
+        _set_cond(ctx, cond)
+        out = ctx.denoise(x, t).cpu()
+        assert ctx.status_flags() == 0, tag
+        err = float((out - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err < 1e-5, (tag, err)
+        ctx.close()
+    for bad in (float("inf"), float("nan")):
+        sdn = {k: v.clone() for k, v in base.items()}
+        sdn["seqTransEncoder.layers.1.linear2.weight"][3, 7] = bad
+        ctx = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3")
+        with pytest.raises(TamfRangeError, match="layers.1.linear2.weight"):
+            ctx.load_state_dict(sdn)
+        ctx.close()
+    for prec in ("bf16x3", "f32"):  # the other formats take any float32
         ctx = TamfContext(_arch_dict(arch), 2, 16, precision=prec)
         ctx.load_state_dict(sd)
         ctx.close()
 
 
-@pytest.mark.parametrize("how", ["activation", "weight"])
+def test_status_word_is_per_context():
+    """Two live f16x3 contexts on one device: an overflow in one raises only ITS bit; reading / clearing one leaves the other's
+    evidence alone; a context created while another's bit is set starts clear and clears nothing (ADVICE r3 / VERDICT r3 #3)."""
+    from oakink2_tamf_amd.hip_backend import STATUS_F16_RANGE
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="rob/w")
+    w1 = sd["seqTransEncoder.layers.0.linear1.weight"]
+    big = _blow_up_ffn_hidden(sd, 3.0e4 / float(w1.abs().max()))
+    cond = _cond(2, 16, "range")
+    x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([10, 700])
+    good = _ctx(arch, sd, 2, 16, "f16x3")
+    bad = _ctx(arch, big, 2, 16, "f16x3")
+    _set_cond(good, cond)
+    _set_cond(bad, cond)
+    ref = good.denoise(x, t).cpu()
+    bad.denoise(x, t)
+    out = good.denoise(x, t).cpu()  # interleaved with the overflowing context on the same device and stream
+    assert good.status_flags(clear=True) == 0            # ... and this read-and-clear must not touch the other word
+    assert bad.status_flags(clear=False) & STATUS_F16_RANGE
+    third = _ctx(arch, sd, 2, 16, "f16x3")               # creating a context clears nobody's evidence
+    assert third.status_flags(clear=False) == 0
+    assert bad.status_flags(clear=True) & STATUS_F16_RANGE
+    assert bad.status_flags() == 0 and good.status_flags() == 0
+    assert torch.equal(out, ref)
+    for c in (good, bad, third):
+        c.close()
+
+
+@pytest.mark.parametrize("how", ["activation", "weight", "nonfinite_weight"])
 def test_module_falls_back_to_f32_when_the_fp16_range_is_left(how):
-    """The drop-in module's default precision is f16x3 with range_check='fallback': out-of-range weights or activations
-    make it repeat the call in f32 - bit-identical to a module built with precision='f32' - and stay there;
-    range_check='raise' raises instead."""
+    """The drop-in module's default precision is f16x3 with range_check='fallback': out-of-range activations (caused by a scaled
+    tensor or by one huge weight - the weight itself loads since round 4) or a non-finite weight make it repeat the call in f32
+    - bit-identical to a module built with precision='f32' - and stay there; range_check='raise' raises instead."""
     from oakink2_tamf_amd.hip_backend import TamfRangeError
     from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
     from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
@@ -260,9 +320,12 @@ def test_module_falls_back_to_f32_when_the_fp16_range_is_left(how):
     if how == "activation":
         w1 = sd["seqTransEncoder.layers.0.linear1.weight"]
         sd = _blow_up_ffn_hidden(sd, 3.0e4 / float(w1.abs().max()))
-    else:
+    elif how == "weight":  # loads (pre-scaled), but the hidden activations it produces leave the fp16 range
         sd = {k: v.clone() for k, v in sd.items()}
-        sd["seqTransEncoder.layers.0.linear1.weight"][0, 0] = 1.0e5
+        sd["seqTransEncoder.layers.0.linear1.weight"][:, 0] = 1.0e6
+    else:  # refused at load -> f32 from the start; fp32 turns the inf into NaN and nan_to_num zeroes it: both modules agree
+        sd = {k: v.clone() for k, v in sd.items()}
+        sd["seqTransEncoder.layers.0.linear1.weight"][0, 0] = float("inf")
     cond = _cond(2, 16, "range")
     batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in cond.items()}
     x = torch.randn(2, 99, 1, 16, generator=torch.Generator().manual_seed(5)).cuda()
@@ -273,7 +336,7 @@ def test_module_falls_back_to_f32_when_the_fp16_range_is_left(how):
     m32 = InterationSegmentMDM(**kw, precision="f32").cuda()
     m32.load_state_dict(sd)
     out, ref = m(x, t, batch), m32(x, t, batch)
-    assert m.active_precision == "f32" and torch.equal(out, ref)
+    assert m.active_precision == "f32" and torch.equal(out, ref) and torch.isfinite(ref).all()
     dif = create_gaussian_diffusion(diffusion_steps=6, noise_schedule="cosine")
     m.load_state_dict(sd)  # new weights: the requested arithmetic is tried again
     assert m.active_precision == "f16x3"

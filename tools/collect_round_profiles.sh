@@ -27,6 +27,7 @@ PY
   done
   python3 - $out $dt <<'PY'
 import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.getcwd())
 out, dt = sys.argv[1:3]
 CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
            ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
@@ -54,7 +55,7 @@ for k in sorted(set(fe) | set(wr)):
     kern[name] = {"fetch_bytes_corrected": f_b, "write_bytes": w_b, "traffic_bytes_per_launch": f_b + w_b}
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also '' --fp32-loops 0 --dtype " + dt,
            "correction": "counters are reported in KiB; gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; counters are fabric-side (Infinity Cache hits included); median over the launches of a kernel class",
-           "dtype": dt, "B": 64, "T": 196, "commit": os.environ.get("TAMF_COMMIT", "unstamped"), "kernels": kern}, open(f"{out}/hbm_traffic_{dt}.json", "w"), indent=1)
+           "dtype": dt, "B": 64, "T": 196, "commit": os.environ.get("TAMF_COMMIT", "unstamped"), "csrc_sha16": __import__("bench").csrc_digest(), "kernels": kern}, open(f"{out}/hbm_traffic_{dt}.json", "w"), indent=1)
 PY
   rm -rf $out/pmc_${dt}_FETCH_SIZE $out/pmc_${dt}_WRITE_SIZE
   python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --also "" --fp32-loops 0 --dtype $dt --profile-out $out/step_profile_$dt.json > $out/step_$dt.log 2>&1

@@ -1,4 +1,4 @@
-"""GPU: ms per DDPM step of the hipGraph loop (B=64, T=196 by default), repeated: loop_time.py [prec] [B] [ddpm_steps] [reps] [tuning]
+"""GPU: ms per DDPM step of the hipGraph loop (B=64, T=196 by default), repeated: loop_time.py [prec] [B] [ddpm_steps] [reps] [tuning] [T]
 (tuning = tamf_set_gemm_tuning value the graph is captured under, e.g. 0x400fffff)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 tune = int(sys.argv[5], 0) if len(sys.argv) > 5 else -1
-T = 196
+T = int(sys.argv[6]) if len(sys.argv) > 6 else 196
 arch = dict(latent_dim=512, ff_size=2048, num_layers=8, num_heads=4)
 sd = O.det_state_dict(O.ARCH_MDM_L, tag="bench/w")
 tab = O.make_tables(N, "cosine")
@@ -30,4 +30,4 @@ ctx.sample_loop(seed=1, out=out); torch.cuda.synchronize()
 ts = []
 for r in range(reps):
     t = time.perf_counter(); ctx.sample_loop(seed=2 + r, out=out); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / N * 1e3)
-print(f"{os.environ.get('TAMF_LIB_OVERRIDE', 'default').split('/')[-1]} {prec} B={B} tuning {tune}: ms/step " + " ".join(f"{t:.3f}" for t in ts), flush=True)
+print(f"{os.environ.get('TAMF_LIB_OVERRIDE', 'default').split('/')[-1]} {prec} B={B} T={T} tuning {tune}: ms/step " + " ".join(f"{t:.3f}" for t in ts), flush=True)
