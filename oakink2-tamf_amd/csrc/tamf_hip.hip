@@ -318,26 +318,34 @@ template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool v
 template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
 
-// Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip.  Used when the clip has 13 MFMA row tiles (193..208 padded
-// rows, i.e. T = 196), K gives an even number of K tiles and the tile count fills the chip's rounds well enough; everything
-// else runs on the 128 x 128 tiles.
-// row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the 13 row tiles - 6 of 13 at
-// 256 columns (5 : 8 spills the Y waves), 2 of 13 at 128 columns (a loader wave is blocked ~850 of the ~1 900 cycles of a 128-column
-// interval while its 11 pieces queue; FFN2 at B = 64: 73.7 us with 4 : 9, 69.5 us with 2 : 11)
+// Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip of NSUB MFMA row tiles.  NSUB = 13 serves the bench shape (T = 196:
+// S = 201, Sp = 208), NSUB = 11 the length the reference's dataset emits (slice_max_len = 160, dataset/interaction_segment.py:291:
+// S = 165, Sp = 168 - the 11th row tile holds 8 rows, the rest of it is clamped on the load side and skipped on the store side);
+// a clip that is up to one row tile shorter than the template runs on it with that tile wasted.  Used when K gives an even number
+// of K tiles and the tile count fills the chip's rounds well enough; everything else runs on the 128 x 128 tiles.
+// row tiles of the X waves (the K tile's loaders): they carry the DMA issue, so they get fewer of the row tiles - 6 of 13 / 5 of 11
+// at 256 columns (5 : 8 spills the Y waves), 2 at 128 columns (a loader wave is blocked ~850 of the ~1 900 cycles of a 128-column
+// interval while its pieces queue; FFN2 at B = 64: 73.7 us with 4 : 9, 69.5 us with 2 : 11)
 #ifndef TAMF_CLIP_XSUB_N2  // (build-time knobs of the A/B runs)
 #define TAMF_CLIP_XSUB_N2 2
 #endif
-#ifndef TAMF_CLIP_XSUB_N4
+#ifndef TAMF_CLIP_XSUB_N4  // X row tiles of a 13-row-tile clip at 256 columns; an 11-row-tile clip gets one less
 #define TAMF_CLIP_XSUB_N4 6
 #endif
-template <int NI> struct ClipXsub { static constexpr int value = NI >= 4 ? TAMF_CLIP_XSUB_N4 : TAMF_CLIP_XSUB_N2; };  // (5 : 8 spills the Y waves at 256 columns)
-#ifndef TAMF_CLIP_XSUB_PARTS  // X : Y row tiles of the 7-row-tile parts (A/B knob; FFN2 at B = 32: 2 : 5 46 us, 3 : 4 60 us, 4 : 3 slower still)
+#ifndef TAMF_CLIP_XSUB_PARTS  // X : Y row tiles of the 7- / 6-row-tile parts (A/B knob; FFN2 at B = 32: 2 : 5 46 us, 3 : 4 60 us, 4 : 3 slower still)
 #define TAMF_CLIP_XSUB_PARTS 2
 #endif
-template <class Op, int NI, class Epi, int NSUB = 13>
+template <int NI, int NSUB, int PARTS>
+struct ClipXsub {
+  static constexpr int value = PARTS > 1 ? TAMF_CLIP_XSUB_PARTS : NI >= 4 ? TAMF_CLIP_XSUB_N4 - (13 - NSUB + 1) / 2 : TAMF_CLIP_XSUB_N2;
+};
+// NSUB: row tiles of a TILE.  PARTS = 1: the tile is a whole clip; PARTS = 2: every clip is cut into its first NSUB row tiles and
+// the rest (NSUB or NSUB - 1 of them), each a tile of its own - for launches whose whole-clip tiles would fill at most half of the CUs
+template <class Op, int NI, class Epi, int NSUB = 13, int PARTS = 1>
 struct ClipLaunch {
-  static constexpr int XSUB = NSUB == 13 ? ClipXsub<NI>::value : TAMF_CLIP_XSUB_PARTS;
+  static constexpr int XSUB = ClipXsub<NI, NSUB, PARTS>::value;
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
+  static constexpr int CLIP_ROWS_MAX = PARTS * C::MT;  // padded rows of the longest clip these tiles hold
   static hipError_t prepare() {
     static bool done[64] = {};
     int dev = 0;
@@ -348,11 +356,16 @@ struct ClipLaunch {
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
   }
-  static bool applies(int n_clips, int Sp, int N, int K, int min_util = 74) {
+  static bool shape_ok(int Sp, int N, int K) {
     if (g_sel & 1) return false;  // kernel benchmark hook: force the 128 x 128 tiles (A/B runs)
-    if (Sp > C::MT || Sp <= C::MT - 16 || N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
+    if (PARTS == 1 ? (Sp > C::MT || Sp <= C::MT - 32) : (Sp > 2 * C::MT || Sp <= 2 * C::MT - 32)) return false;
+    if (N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
     const int KT = (K * Op::EB) / GEMM_BKB;
-    if (KT < 2 || (KT & 1)) return false;
+    return KT >= 2 && !(KT & 1);
+  }
+  static bool applies(int n_clips, int Sp, int N, int K, int min_util = 74) {
+    static_assert(PARTS == 1, "whole-clip tiles");
+    if (!shape_ok(Sp, N, K)) return false;
     const int cus = g_wg_slots / 2, tiles = n_clips * (N / C::BN), rounds = (tiles + cus - 1) / cus;
     return tiles * 100 >= rounds * cus * ((g_sel & 1024) ? 50 : min_util);  // >= 74 % of the workgroup slots of its rounds are used (A/B: 50 %)
   }
@@ -360,24 +373,27 @@ struct ClipLaunch {
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
-    static_assert(NSUB == 13 || NSUB == 7, "whole clips (13 row tiles) or the 7 + 6 row-tile parts of one");
-    constexpr int parts = NSUB == 13 ? 1 : 2, split_rows = NSUB == 13 ? 0 : NSUB * 16;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, parts * n_clips * (N / C::BN), split_rows,
+    static_assert(PARTS == 1 || PARTS == 2, "whole clips or their two row parts");
+    constexpr int split_rows = PARTS == 1 ? 0 : NSUB * 16;
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, PARTS * n_clips * (N / C::BN), split_rows,
                         g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
     const int cus = g_wg_slots / 2;
     hipLaunchKernelGGL((clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
   }
-  // row-part tiles (NSUB = 7): when whole-clip tiles would use at most half of the CUs and the parts fit one round
+  // row-part tiles: when whole-clip tiles would use at most half of the CUs and the parts fit one round
   static bool applies_parts(int n_clips, int Sp, int N, int K) {
-    if (g_sel & 1) return false;
-    if (Sp != 208 || N % C::BN != 0 || (K * Op::EB) % GEMM_BKB != 0) return false;
-    const int KT = (K * Op::EB) / GEMM_BKB;
-    if (KT < 2 || (KT & 1)) return false;
+    static_assert(PARTS == 2, "row-part tiles");
+    if (!shape_ok(Sp, N, K) || Sp <= C::MT) return false;
     const int cus = g_wg_slots / 2, whole = n_clips * (N / C::BN);
     return whole * 2 <= cus;
   }
 };
+// Bind NS (whole-clip row tiles: 13 or 11) and NSP (row tiles of the first of two row parts: 7 or 6) for a clip of Sp padded rows
+// and run the statement(s) that follow Sp_ (variadic: template argument lists carry commas); nothing runs for other clip lengths
+#define TAMF_CLIP_NSUB(Sp_, ...)                                                                \
+  if ((Sp_) > 176 && (Sp_) <= 208) { constexpr int NS = 13, NSP = 7; (void)NSP; (void)NS; __VA_ARGS__; } \
+  else if ((Sp_) > 144 && (Sp_) <= 176) { constexpr int NS = 11, NSP = 6; (void)NSP; (void)NS; __VA_ARGS__; }
 
 // share of the workgroup slots of its rounds that a launch of `tiles` workgroups uses
 static inline double round_util(int tiles, int slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
@@ -409,6 +425,20 @@ static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStrea
     default: return hipErrorInvalidValue;
   }
 }
+// the clip-tile kernels of one clip length (NS whole-clip row tiles, NSP row tiles of a row part)
+template <class Op, int NS, int NSP>
+static hipError_t prepare_clip() {
+  hipError_t e;
+  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NS>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::prepare()) != hipSuccess) return e;
+  if constexpr (Op::PREC == 0 || NS == 13) {  // the QKV projection on clip tiles: f32 (the 16-bit modes: A/B partner at T = 196 only)
+    if ((e = ClipLaunch<Op, 2, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 4, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 2, EpiVt<Op>, NS>::prepare()) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 template <class Op>
 static hipError_t prepare_all() {
   hipError_t e;
@@ -423,13 +453,9 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 32, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiQK<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 4, EpiQK<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiVt<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiStoreF32>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiStoreF32, 7>::prepare()) != hipSuccess) return e;
+  if ((e = prepare_clip<Op, 13, 7>()) != hipSuccess) return e;
+  if ((e = prepare_clip<Op, 11, 6>()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;  // (A/B partner and test hook, T = 196 only)
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
@@ -438,6 +464,8 @@ static hipError_t prepare_all() {
   {
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_res_kernel<Op, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   }
@@ -466,9 +494,11 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
     hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nw * 64), lds, st, aa);                \
     return hipGetLastError();                                                                              \
   }
-      TAMF_TRY_RES(64, 4)   // up to 128 keys (the dataset's clips: T <= 160 needs 7)
-      TAMF_TRY_RES(64, 7)   // up to 224 keys
+      TAMF_TRY_RES(64, 4)   // up to 128 keys
+      TAMF_TRY_RES(64, 6)   // up to 192 keys: the dataset's clips (T = 160: S = 165, 11 key tiles of the 12)
+      TAMF_TRY_RES(64, 7)   // up to 224 keys (T = 196)
       TAMF_TRY_RES(128, 4)
+      TAMF_TRY_RES(128, 6)
       TAMF_TRY_RES(128, 7)
 #undef TAMF_TRY_RES
     }
@@ -944,19 +974,27 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // clip tiles of 128 columns = one head of Q, K or V: the Q and K columns as one launch (8 tiles per clip), the V columns
       // as a second one with the MFMA operands exchanged (V^T rows straight from the accumulators); else the 128 x 128 tiles
       // (f32: 174.5 against 190 us at B = 64; the 16-bit modes: 62.5 against 62 us, they stay on the 128 x 128 tiles; 128 = force)
-      if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128 && ClipLaunch<Op, 2, EpiQK<Op>>::applies(B, Sp, 2 * d, d) &&
-          ClipLaunch<Op, 2, EpiVt<Op>>::applies(B, Sp, d, d)) {
-        EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}};
-        if (ClipLaunch<Op, 4, EpiQK<Op>>::applies(B, Sp, 2 * d, d))  // the Q | K columns on 256-column tiles where they fill their rounds (f32, B = 64: 174.5 against 179 us)
-          HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
-        else
-          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
-        const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
-        EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}};
-        mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
-        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
-        mark("gemm_v", BS * 2.0 * dd * dd);
-      } else {
+      bool on_clip = false;
+      if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128) {
+        TAMF_CLIP_NSUB(Sp, {
+          if constexpr (Op::PREC == 0 || NS == 13) {
+            if (ClipLaunch<Op, 2, EpiQK<Op>, NS>::applies(B, Sp, 2 * d, d) && ClipLaunch<Op, 2, EpiVt<Op>, NS>::applies(B, Sp, d, d)) {
+              EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}};
+              if (ClipLaunch<Op, 4, EpiQK<Op>, NS>::applies(B, Sp, 2 * d, d))  // the Q | K columns on 256-column tiles where they fill their rounds (f32, B = 64: 174.5 against 179 us)
+                HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+              else
+                HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+              const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
+              EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}};
+              mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
+              HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>, NS>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
+              mark("gemm_v", BS * 2.0 * dd * dd);
+              on_clip = true;
+            }
+          }
+        })
+      }
+      if (!on_clip) {
         EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}};
         HIPCHK(ctx, gemm128<Op>(ga, ep, st));
         mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
@@ -970,13 +1008,20 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
       // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes keep the fused 64 x d tile (40 against 25 + 17 us)
-      if ((Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32 && ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, d)) {
-        EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
-        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
-        mark("gemm_outproj", BS * 2.0 * dd * dd);
-        launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
-        mark("outproj_residual_ln", 0.0);
-      } else {
+      bool on_clip = false;
+      if ((Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32) {
+        TAMF_CLIP_NSUB(Sp, {
+          if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d)) {
+            EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
+            HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
+            mark("gemm_outproj", BS * 2.0 * dd * dd);
+            launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
+            mark("outproj_residual_ln", 0.0);
+            on_clip = true;
+          }
+        })
+      }
+      if (!on_clip) {
         EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f, {w.Wout.inv_scale, ctx->status}};
         HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
         mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
@@ -985,12 +1030,19 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     {
       GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
       EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}};
-      if ((g_sel & 32) && ClipLaunch<Op, 2, EpiBiasAct<Op>>::applies(B, Sp, ff, d))  // A/B: 128-column tiles (half the bytes per store burst)
+      bool on_clip = false;
+      if ((g_sel & 32) && ClipLaunch<Op, 2, EpiBiasAct<Op>>::applies(B, Sp, ff, d)) {  // A/B: 128-column tiles (half the bytes per store burst)
         HIPCHK(ctx, (ClipLaunch<Op, 2, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
-      else if (!(g_sel & 8) && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(B, Sp, ff, d))
-        HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
-      else
-        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+        on_clip = true;
+      } else if (!(g_sel & 8)) {
+        TAMF_CLIP_NSUB(Sp, {
+          if (ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::applies(B, Sp, ff, d)) {
+            HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+            on_clip = true;
+          }
+        })
+      }
+      if (!on_clip) HIPCHK(ctx, gemm128<Op>(ga, ep, st));
       mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
     }
     {
@@ -1000,19 +1052,26 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
       // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
       // (split modes: from 50 % of the slots - at 32 clips per GPU 128 clip tiles beat 208 tiles of 128 x 128: 1.645 -> 1.60 ms per step)
-      const bool clip2 = (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2) &&
-                         ClipLaunch<Op, 2, EpiStoreF32>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74);
+      int clip2 = 0;  // 1 = whole-clip tiles, 2 = row-part tiles
+      if ((Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
+        TAMF_CLIP_NSUB(Sp, {
+          if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74))
+            clip2 = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff) ? 2 : 1;
+        })
+      }
       if ((Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE, {w.W2.inv_scale, ctx->status}};
-        // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 row-tile parts of every clip
-        // as tiles of their own fill the round (58 -> ~40 us; same bits)
-        if (clip2 && ClipLaunch<Op, 2, EpiStoreF32, 7>::applies_parts(B, Sp, d, ff))
-          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, 7>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
-        else if (clip2)
-          HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
-        else
+        // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 (6 + 5 at T = 160) row-tile parts
+        // of every clip as tiles of their own fill the round (58 -> ~40 us; same bits)
+        if (clip2) {
+          TAMF_CLIP_NSUB(Sp, {
+            if (clip2 == 2) HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
+            else HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
+          })
+        } else {
           HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+        }
         mark("gemm_ffn2", BS * 2.0 * dd * ff);
         launch_residual_ln<Op>(ctx, w.g2, w.be2, st);
         mark("ffn2_residual_ln", 0.0);
@@ -1306,14 +1365,28 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
     e = gemm_ln<Op>(ga, ep, st);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
-    // M = n * 208 rows: the clip-aligned tiles the encoder layers use at T = 196 (same selection as enqueue_step)
+    // M = n * 208 rows (T = 196) or n * 168 rows (T = 160): the clip-aligned tiles the encoder layers use (same selection as
+    // enqueue_step; 32 clips or fewer: the row-part tiles)
     const int nc = M / 208;
-    if (M % 208 == 0 && N % 256 == 0 && ClipLaunch<Op, 4, EpiStoreF32>::applies(nc, 208, N, Kp))
+    bool done = false;
+    if (M % 208 == 0 && N % 256 == 0 && ClipLaunch<Op, 4, EpiStoreF32>::applies(nc, 208, N, Kp)) {
       e = ClipLaunch<Op, 4, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
-    else if (M % 208 == 0 && ClipLaunch<Op, 2, EpiStoreF32>::applies(nc, 208, N, Kp))
-      e = ClipLaunch<Op, 2, EpiStoreF32>::launch(nullptr, ao, Kp, wo, Kp, nc, 208, N, Kp, ep, st);
-    else
-      e = gemm128<Op>(ga, ep, st);
+      done = true;
+    } else {
+      const int sp = M % 208 == 0 ? 208 : (M % 168 == 0 ? 168 : 0);
+      if (sp) {
+        TAMF_CLIP_NSUB(sp, {
+          if (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(M / sp, sp, N, Kp)) {
+            e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ao, Kp, wo, Kp, M / sp, sp, N, Kp, ep, st);
+            done = true;
+          } else if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(M / sp, sp, N, Kp)) {
+            e = ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ao, Kp, wo, Kp, M / sp, sp, N, Kp, ep, st);
+            done = true;
+          }
+        })
+      }
+    }
+    if (!done) e = gemm128<Op>(ga, ep, st);
   }
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
   if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "sync failed");

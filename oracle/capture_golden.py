@@ -116,10 +116,10 @@ def capture_schedule():
     np.savez_compressed(os.path.join(OUT_DIR, "schedule.npz"), **out)
 
 
-def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfinite=False):
-    sd = O.det_state_dict(arch, tag=f"{name}/w")
+def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfinite=False, sd_fn=O.det_state_dict, cond_fn=O.det_cond):
+    sd = sd_fn(arch, tag=f"{name}/w")
     m = _ref_model(arch, sd)
-    cond = O.det_cond(B, T, nobj=nobj, tag=f"{name}/c", arch=arch)
+    cond = cond_fn(B, T, nobj=nobj, tag=f"{name}/c", arch=arch)
     x = torch.from_numpy(det.det_normal(f"{name}/x", (B, arch.input_dim, 1, T)))
     if nonfinite:
         # exercise the three nan_to_num sites (interaction_segment_mdm.py:158,166,173)
@@ -145,13 +145,14 @@ def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfini
     np.savez_compressed(os.path.join(OUT_DIR, f"forward_{name}.npz"), **fix)
 
 
-def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_noise: bool, dump_steps=None):
+def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_noise: bool, dump_steps=None, sd_fn=O.det_state_dict,
+                 cond_fn=O.det_cond):
     from oakink2_tamf.model.diffusion_util import create_gaussian_diffusion
     from oakink2_tamf.model.diffusion import gaussian_diffusion as gd
 
-    sd = O.det_state_dict(arch, tag=f"{name}/w")
+    sd = sd_fn(arch, tag=f"{name}/w")
     m = _ref_model(arch, sd)
-    cond = O.det_cond(B, T, tag=f"{name}/c", arch=arch)
+    cond = cond_fn(B, T, tag=f"{name}/c", arch=arch)
     batch = _ref_batch(cond, m)
     shape = (B, arch.input_dim, 1, T)
     dif = create_gaussian_diffusion(diffusion_steps=steps, noise_schedule="cosine")
@@ -433,6 +434,17 @@ def capture_loop_arch_mdm_1000():
     capture_loop("arch_mdm_b4_t64_1000", O.ARCH_MDM, B=4, T=64, steps=1000, store_noise=False, dump_steps=[0, 499, 998, 999])
 
 
+def capture_stress():
+    """the fp32-tolerance gate on trained-like dynamic range, at the dataset's clip length (T = 160), arch_mdm_l, B = 2:
+    (i) real conditioning magnitudes on the default weights, (ii) those plus LayerNorm gains in [0.2, 5] and x30 outlier rows;
+    each: one evaluation at t in {0, 500, 999} + a 50-step loop (states after steps 0, 24, 48 and the final sample)."""
+    capture_forward("stress_cond_t160", O.ARCH_MDM_L, B=2, T=160, ts=[0, 500, 999], cond_fn=O.det_cond_stress)
+    capture_loop("stress_cond_b2_t160_50", O.ARCH_MDM_L, B=2, T=160, steps=50, store_noise=False, dump_steps=[0, 24, 48, 49], cond_fn=O.det_cond_stress)
+    capture_forward("stress_weights_t160", O.ARCH_MDM_L, B=2, T=160, ts=[0, 500, 999], sd_fn=O.det_state_dict_stress, cond_fn=O.det_cond_stress)
+    capture_loop("stress_weights_b2_t160_50", O.ARCH_MDM_L, B=2, T=160, steps=50, store_noise=False, dump_steps=[0, 24, 48, 49],
+                 sd_fn=O.det_state_dict_stress, cond_fn=O.det_cond_stress)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -458,6 +470,7 @@ def main():
     capture_loop("tiny_1000", O.ARCH_TINY, B=2, T=16, steps=1000, store_noise=False)
     capture_loop_arch_mdm_l_1000()
     capture_loop_arch_mdm_1000()
+    capture_stress()
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()

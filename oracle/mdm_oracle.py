@@ -230,6 +230,42 @@ def det_cond(B: int, T: int, nobj: int = 2, tag: str = "c0", arch: Arch = ARCH_M
     }
 
 
+def det_state_dict_stress(arch: Arch, tag: str = "w0") -> Dict[str, torch.Tensor]:
+    """det_state_dict with the dynamic range of a TRAINED network: LayerNorm gains
+    log-uniform in [0.2, 5], and about 1 % of the rows of every layer's `linear1.weight` / `self_attn.in_proj_weight` scaled x30
+    (outlier channels).  Seed-free like everything in oracle/det.py; used for the stress fixtures of the fp32-tolerance gate."""
+    sd = det_state_dict(arch, tag)
+    for name in list(sd):
+        if ".norm" in name and name.endswith(".weight"):
+            u = det.det_uniform(f"{tag}/stress-gamma/{name}", tuple(sd[name].shape), 1.0)  # in [-1, 1)
+            sd[name] = torch.from_numpy(np.exp(u * math.log(5.0)).astype(np.float32))  # log-uniform in [0.2, 5)
+        elif name.endswith("linear1.weight") or name.endswith("in_proj_weight"):
+            rows = sd[name].shape[0]
+            pick = det.det_uniform(f"{tag}/stress-rows/{name}", (rows,), 1.0) > 0.98  # ~1 % of the rows
+            w = sd[name].clone()
+            w[torch.from_numpy(pick)] *= 30.0
+            sd[name] = w
+    return sd
+
+
+def det_cond_stress(B: int, T: int, nobj: int = 2, tag: str = "c0", arch: Arch = ARCH_MDM) -> Dict[str, object]:
+    """det_cond with the magnitudes of real conditioning: CLIP text features of norm 10, object trajectories as
+    [translation in metres | rot6d of a unit rotation] (obj_input_dim = 9: dev_fn/transform/rotation.py rot6d = the first two
+    columns of R, row-major), hand shape betas ~ N(0, 1)."""
+    c = det_cond(B, T, nobj=nobj, tag=tag, arch=arch)
+    te = c["text_embedding"]
+    c["text_embedding"] = te / te.norm(dim=-1, keepdim=True) * 10.0
+    raw = det.det_normal(f"{tag}/stress-traj", (B, nobj, T, 12))
+    tsl = 0.3 * raw[..., :3]
+    a1, a2 = raw[..., 3:6], raw[..., 6:9]
+    b1 = a1 / np.linalg.norm(a1, axis=-1, keepdims=True)
+    a2 = a2 - (b1 * a2).sum(-1, keepdims=True) * b1
+    b2 = a2 / np.linalg.norm(a2, axis=-1, keepdims=True)
+    rot6d = np.stack([b1, b2], axis=-1).reshape(B, nobj, T, 6)  # columns of R interleaved row-major: (r00, r01, r10, r11, r20, r21)
+    c["obj_traj"] = torch.from_numpy(np.ascontiguousarray(np.concatenate([tsl, rot6d], axis=-1).astype(np.float32)))
+    return c
+
+
 # --------------------------------------------------------------------------------------
 # Denoiser forward (G) and refiner trunk (R)
 # --------------------------------------------------------------------------------------

@@ -270,3 +270,122 @@ def test_kernel_selections_give_the_same_bits(full, prec):
     finally:
         lib().tamf_set_gemm_tuning(-1)
         ctx.close()
+
+
+# ---- T = 160: the only clip length the reference's dataset emits (dataset/interaction_segment.py:291, slice_max_len = 160) ------------
+# S = 165, padded to Sp = 168 rows = 10.5 MFMA row tiles: clip tiles of 11 row tiles (6 + 5 as row parts at 32 clips per GPU), the
+# resident-K attention with 12 key tiles, 64-row LayerNorm blocks that straddle clips, V^T rows of 192 keys.
+T_DS = 160
+
+
+@pytest.fixture(scope="module")
+def full160():
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    cond = O.det_cond(B_FULL, T_DS, tag="full160/c", arch=arch)
+    g = torch.Generator().manual_seed(160)
+    x = torch.randn(B_FULL, 99, 1, T_DS, generator=g)
+    t = torch.randint(0, 1000, (B_FULL,), generator=g)
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd, arch, x, t, cond)
+    return dict(arch=arch, sd=sd, cond=cond, x=x, t=t, ref=ref)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_forward_b64_t160_vs_oracle(full160, prec):
+    ctx = _make_ctx(full160["arch"], full160["sd"], B_FULL, T_DS, prec)
+    _set_cond(ctx, full160["cond"])
+    out = ctx.denoise(full160["x"], full160["t"]).cpu()
+    assert torch.isfinite(out).all()
+    per_clip = (out - full160["ref"]).abs().amax(dim=(1, 2, 3))
+    err = float(per_clip.max())
+    print(f"fullsize forward[{prec}] B=64 T=160: max|err| = {err:.3e} (worst clip {int(per_clip.argmax())})")
+    assert err < FWD_TOL[prec], (prec, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_loop5_b64_t160_vs_oracle(full160, prec):
+    from oracle import det
+    from oracle import mdm_oracle as O
+
+    N = 5
+    tab = O.make_tables(N, "cosine")
+    shape = (B_FULL, 99, 1, T_DS)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag("full160/eps", k), shape) for k in range(N + 1)]))
+    with torch.no_grad():
+        ref = O.sample_loop(full160["sd"], full160["arch"], tab, full160["cond"], shape, lambda k: draws[k])
+    ctx = _make_ctx(full160["arch"], full160["sd"], B_FULL, T_DS, prec, n_steps=N)
+    _set_cond(ctx, full160["cond"])
+    out = ctx.sample_loop(noise=draws).cpu()
+    err = float((out - ref).abs().max())
+    print(f"fullsize 5-step loop[{prec}] T=160: max|err| = {err:.3e}")
+    assert err < LOOP_TOL[prec], (prec, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_clip_in_b64_t160_equals_clip_alone(full160, prec):
+    """Sharding invariance at T = 160: clip i of the B = 64 batch (11-row-tile clip tiles) vs alone (128 x 128 tiles) vs inside
+    the B = 32 half (6 + 5 row-part tiles, attention on split query ranges) - bit for bit."""
+    N = 3
+    ctx = _make_ctx(full160["arch"], full160["sd"], B_FULL, T_DS, prec, n_steps=N)
+    _set_cond(ctx, full160["cond"])
+    whole = ctx.sample_loop(noise=None, seed=7, clip_id_base=1000).cpu()
+    for i in (0, 21, 63):
+        _set_cond(ctx, _sub(full160["cond"], slice(i, i + 1)))
+        one = ctx.sample_loop(noise=None, seed=7, clip_id_base=1000 + i).cpu()
+        assert torch.equal(one[0], whole[i]), (prec, i, float((one[0] - whole[i]).abs().max()))
+    _set_cond(ctx, _sub(full160["cond"], slice(32, 64)))
+    half = ctx.sample_loop(noise=None, seed=7, clip_id_base=1032).cpu()
+    assert torch.equal(half, whole[32:])
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B", [32, 48])
+def test_forward_other_batch_sizes_t160(full160, prec, B):
+    ctx = _make_ctx(full160["arch"], full160["sd"], B, T_DS, prec)
+    _set_cond(ctx, _sub(full160["cond"], slice(0, B)))
+    out = ctx.denoise(full160["x"][:B], full160["t"][:B]).cpu()
+    err = float((out - full160["ref"][:B]).abs().max())
+    print(f"fullsize forward[{prec}] B={B} T=160: max|err| = {err:.3e}")
+    assert err < FWD_TOL[prec], (prec, B, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_kernel_selections_give_the_same_bits_t160(full160, prec):
+    from oakink2_tamf_amd.hip_backend import lib
+
+    B = 48
+    ctx = _make_ctx(full160["arch"], full160["sd"], B, T_DS, prec)
+    _set_cond(ctx, _sub(full160["cond"], slice(0, B)))
+    try:
+        ref = ctx.denoise(full160["x"][:B], full160["t"][:B]).cpu()
+        for sel, what in SELECTIONS.items():
+            lib().tamf_set_gemm_tuning((sel << 20) | 0xFFFFF)
+            got = ctx.denoise(full160["x"][:B], full160["t"][:B]).cpu()
+            assert torch.equal(got, ref), (prec, hex(sel), what, float((got - ref).abs().max()))
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+        ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("clips", [64, 32])
+def test_gemm_clip_tiles_exact_integers_t160(prec, clips):
+    """The 11-row-tile clip tiles (64 clips) and their 6 + 5 row parts (32 clips) on M = clips x 168 rows: exact integers, so any slip
+    in the clamped half row tile, the part boundaries or the tile -> (clip, column) map is a wrong integer."""
+    from oakink2_tamf_amd import hip_backend as hb
+
+    M, N, K = clips * 168, 512, 128
+    g = torch.Generator().manual_seed(6)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    b = torch.randint(-8, 9, (N,), generator=g).float()
+    got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), 0).cpu()
+    ref = (a.long() @ w.long().t() + b.long()).float()
+    assert torch.equal(got, ref), (prec, clips, int((got != ref).sum()))

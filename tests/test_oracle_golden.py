@@ -165,3 +165,43 @@ def test_philox_normal_moments_and_shard_independence():
     assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02
     b = O.philox_normal(7, np.arange(4, 8), 3, 99, 64)
     np.testing.assert_array_equal(a[4:], b)
+
+
+# ---- stress fixtures (round 4): trained-like dynamic range at the dataset's clip length, captured from the reference ------------------
+STRESS = {"stress_cond": O.det_state_dict, "stress_weights": O.det_state_dict_stress}
+
+
+@pytest.mark.parametrize("kind", list(STRESS))
+def test_stress_forward_matches_reference(kind):
+    """arch_mdm_l, B = 2, T = 160: CLIP features of norm 10, object trajectories in metres + unit rot6d (both kinds); LayerNorm gains
+    in [0.2, 5] and x30 outlier rows in linear1 / in_proj (stress_weights).  Gate 1e-5 relative to max |ref| - the reference's own
+    fp32 <-> fp64 distance on these weights is 3.5e-6 of |ref|max = 3.9 (oracle/capture_golden.py capture_stress)."""
+    name = f"{kind}_t160"
+    fix = load_golden(f"forward_{name}.npz")
+    arch = O.ARCH_MDM_L
+    sd = STRESS[kind](arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    assert abs(float(cond["text_embedding"].norm(dim=-1)[0]) - 10.0) < 1e-3
+    x = torch.from_numpy(fix["x"])
+    for t in fix["ts"]:
+        out = O.denoiser_forward(sd, arch, x, torch.full((x.shape[0],), int(t), dtype=torch.long), cond).numpy()
+        ref = fix[f"out/t{int(t)}"]
+        assert np.abs(out - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), (kind, int(t))
+
+
+@pytest.mark.parametrize("kind", list(STRESS))
+def test_stress_loop50_matches_reference(kind):
+    from oracle import det
+
+    name = f"{kind}_b2_t160_50"
+    fix = load_golden(f"loop_{name}.npz")
+    arch = O.ARCH_MDM_L
+    sd = STRESS[kind](arch, tag=f"{name}/w")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 160)
+    tab = O.make_tables(50, "cosine")
+    dump = []
+    O.sample_loop(sd, arch, tab, cond, shape, lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{name}/eps", k), shape)), dump=dump)
+    for s in fix["dump_steps"]:
+        ref = fix[f"dump/{int(s)}"]
+        assert np.abs(dump[int(s)].numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), (kind, int(s))
