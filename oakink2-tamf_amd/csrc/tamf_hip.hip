@@ -18,6 +18,7 @@
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
+#include "tamf_gemm_rowblock.h"
 #include "tamf_geom.h"
 #include "tamf_misc.h"
 
@@ -37,6 +38,7 @@ static std::string g_noctx_err;
 
 struct OperandBuf {
   void* p = nullptr;
+  void* packed = nullptr;  // fragment-major copy for the row-block kernels (tamf_gemm_rowblock.h): out-proj and FFN2 weights, d = 512
   float inv_scale = 1.0f;  // f16x3 weights are stored scaled by a power of two (upload_operand); this is its inverse, applied by the epilogue
 };
 
@@ -236,7 +238,8 @@ static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too,
-// 512 = streaming attention kernel in the 16-bit modes too, 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds
+// 512 = streaming attention kernel in the 16-bit modes too, 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds,
+// 2048 = no row-block kernels: the LayerNorm-fused GEMMs on the LDS-staged tiles of rounds 1 - 3 (set by a tuning word whose low 20 bits are 0x7FFFF)
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -413,8 +416,38 @@ static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st
   }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
+// Row-block kernel (tamf_gemm_rowblock.h): rows per workgroup = the smallest of 32 / 48 / 64 that still fits one round of the CUs
+// (fewer rows per workgroup = more CUs busy and less MFMA work behind the same weight stream); beyond one round: 64
+template <class Op, int MI>
+static hipError_t rowblock_launch1(const RowblockArgs<Op>& ra, const EpiLN<Op>& epi, hipStream_t st) {
+  constexpr int BM = MI * 16, SMEM = RowblockCfg<Op>::NSTG * BM * GEMM_BKB + 2 * BM * 16 * 4;
+  static bool done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(dev >= 0 && dev < 64 && done[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void*)rowblock_ln_kernel<Op, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) done[dev] = true;
+  }
+  hipLaunchKernelGGL((rowblock_ln_kernel<Op, MI>), dim3((ra.M + BM - 1) / BM), dim3(512), SMEM, st, ra, epi);
+  return hipGetLastError();
+}
 template <class Op>
-static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st) {
+static bool rowblock_applies(const GemmArgs<Op>& ga, const void* packed) {
+  if (!packed || (g_sel & (1 | 2048)) || ga.N != 512 || (ga.K * Op::EB) % GEMM_BKB != 0) return false;
+  return (ga.K * Op::EB) / GEMM_BKB >= 8;
+}
+template <class Op>
+static hipError_t rowblock_launch(const GemmArgs<Op>& ga, const void* packed, const EpiLN<Op>& epi, hipStream_t st) {
+  const RowblockArgs<Op> ra{ga.A, ga.lda, (const char*)packed, ga.M, ga.K};
+  const int cus = g_wg_slots / 2;
+  if ((ga.M + 31) / 32 <= cus) return rowblock_launch1<Op, 2>(ra, epi, st);
+  if ((ga.M + 47) / 48 <= cus) return rowblock_launch1<Op, 3>(ra, epi, st);
+  return rowblock_launch1<Op, 4>(ra, epi, st);
+}
+template <class Op>
+static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st, const void* packed = nullptr) {
+  if (rowblock_applies<Op>(ga, packed)) return rowblock_launch<Op>(ga, packed, epi, st);
   switch (ga.N) {
     case 128: return GemmLaunch<Op, 64, 128, EpiLN<Op>>::launch(ga, epi, st);
     case 256: return GemmLaunch<Op, 64, 256, EpiLN<Op>>::launch(ga, epi, st);
@@ -644,6 +677,16 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   delete ctx;
 }
 
+// fragment-major copy of a [512][K] operand matrix (tamf_gemm_rowblock.h)
+static int pack_rowblock(tamf_ctx* ctx, OperandBuf* ob, int K, hipStream_t st) {
+  const size_t bytes = (size_t)512 * K * ctx->EB;
+  TRY(dev_alloc(ctx, &ob->packed, bytes));
+  const long pieces = (long)bytes / 16;
+  TAMF_WITH_OP(ctx->prec, hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d(pieces), dim3(256), 0, st, (const typename Op::elem_t*)ob->p, K, K, (char*)ob->packed));
+  HIPCHK(ctx, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------------
@@ -730,6 +773,10 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout, (p + ".self_attn.out_proj.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2, (p + ".linear2.weight").c_str()));
+    if (d == 512) {  // fragment-major copies for the row-block LayerNorm GEMMs
+      TRY(pack_rowblock(ctx, &w.Wout, d, st));
+      TRY(pack_rowblock(ctx, &w.W2, ff, st));
+    }
     TRY(upload_f32(ctx, p + ".self_attn.in_proj_bias", &w.b_in));
     TRY(upload_f32(ctx, p + ".self_attn.out_proj.bias", &w.b_out));
     TRY(upload_f32(ctx, p + ".linear1.bias", &w.b1));
@@ -1007,9 +1054,12 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
-      // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes keep the fused 64 x d tile (40 against 25 + 17 us)
+      // Round 4: the row-block kernel with LayerNorm inside (tamf_gemm_rowblock.h; d = 512) in every mode.  Where it does not apply
+      // (d < 512, selection bit 2048) - f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes: the fused
+      // LDS-staged 64 x d tile (40 against 25 + 17 us).  Selection bit 16 forces the two-kernel form.
       bool on_clip = false;
-      if ((Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32) {
+      const bool rb = rowblock_applies<Op>(ga, w.Wout.packed) && !(g_sel & 16);
+      if (!rb && (Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32) {
         TAMF_CLIP_NSUB(Sp, {
           if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d)) {
             EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
@@ -1023,7 +1073,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       }
       if (!on_clip) {
         EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_op.p, 1e-5f, {w.Wout.inv_scale, ctx->status}};
-        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st, w.Wout.packed));
         mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
       }
     }
@@ -1052,14 +1102,17 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
       // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
       // (split modes: from 50 % of the slots - at 32 clips per GPU 128 clip tiles beat 208 tiles of 128 x 128: 1.645 -> 1.60 ms per step)
+      // Round 4: the row-block kernel (LayerNorm inside, weights streamed L2 -> registers) in every mode where it applies (d = 512);
+      // selection bit 256 forces the two-kernel form, 2048 the kernels of rounds 1 - 3.
       int clip2 = 0;  // 1 = whole-clip tiles, 2 = row-part tiles
-      if ((Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
+      const bool rb = rowblock_applies<Op>(ga, w.W2.packed) && !(g_sel & 256);
+      if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
         TAMF_CLIP_NSUB(Sp, {
           if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74))
             clip2 = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff) ? 2 : 1;
         })
       }
-      if ((Op::SPLIT || clip2) && ctx->tmp32) {
+      if (!rb && (Op::SPLIT || clip2) && ctx->tmp32) {
         // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
         EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE, {w.W2.inv_scale, ctx->status}};
         // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 (6 + 5 at T = 160) row-tile parts
@@ -1077,7 +1130,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         mark("ffn2_residual_ln", 0.0);
       } else {
         EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_op.p, 1e-5f, {w.W2.inv_scale, ctx->status}};
-        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st));
+        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st, w.W2.packed));
         mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
       }
     }
@@ -1362,7 +1415,13 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   hipError_t e;
   if (ln) {
     EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, 1e-5f};
-    e = gemm_ln<Op>(ga, ep, st);
+    char* packed = nullptr;
+    if (N == 512) {  // the row-block kernel reads a fragment-major copy of the weights (what tamf_finalize_weights prepares)
+      packed = (char*)tb.get((size_t)N * Kp * Op::EB);
+      if (!packed) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+      hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d((long)N * Kp * Op::EB / 16), dim3(256), 0, st, wo, Kp, Kp, packed);
+    }
+    e = gemm_ln<Op>(ga, ep, st, packed);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
     // M = n * 208 rows (T = 196) or n * 168 rows (T = 160): the clip-aligned tiles the encoder layers use (same selection as
@@ -1487,6 +1546,12 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
   hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(on / 8), dim3(256), 0, st, x, on, 3u);
   hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, 4u);
   GemmArgs<Op> ga{a, K, w, K, M, N, K, 0};
+  char* wpacked = nullptr;
+  if (epi_kind == 2 && N == 512) {
+    wpacked = (char*)tb.get((size_t)wn * Op::EB);
+    if (!wpacked) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
+    hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d(wn * Op::EB / 16), dim3(256), 0, st, w, K, K, wpacked);
+  }
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
   hipError_t e = hipSuccess;
@@ -1494,7 +1559,7 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
     if (it == 0) (void)hipEventRecord(e0, st);
     if (epi_kind == 2) {
       EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, 1e-5f};
-      e = gemm_ln<Op>(ga, ep, st);
+      e = gemm_ln<Op>(ga, ep, st, wpacked);
     } else if (epi_kind == 3) {
       EpiStoreF32 ep{vec, x, N, ACT_NONE};
       if (M % 208 == 0 && ClipLaunch<Op, 2, EpiStoreF32>::applies(M / 208, 208, N, K))
@@ -1726,8 +1791,12 @@ extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..30: kernel-selection overrides (g_sel).
   // The words are process-global and a captured loop graph has the selection of its capture time baked in, so every live
   // context's graph is retired here: the next tamf_sample_loop re-captures with the new selection (same as tamf_denoise).
-  const int sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
-  const int rot = (krot >= 0 && (krot & 0xFFFFF) != 0xFFFFF) ? (krot & 0xFFFFF) : -1;
+  // (selection bit 2048 - no row-block kernels - has no room above bit 30: it is "low 20 bits = 0x7FFFF", i.e. all ones but bit 19)
+  int sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
+  const int low = krot & 0xFFFFF;
+  int rot = -1;
+  if (krot >= 0 && low == 0x7FFFF) sel |= 2048;
+  else if (krot >= 0 && low != 0xFFFFF) rot = low;
   if (sel != g_sel || rot != g_krot) {
     std::lock_guard<std::mutex> lk(g_live_mu);
     for (tamf_ctx* c : g_live_ctx) (void)retire_graph(c);
