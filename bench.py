@@ -100,6 +100,90 @@ def hbm_traffic(dtype, kernel, B, T):
     return None, None, None
 
 
+class PowerTrace:
+    """Package power / shader clock of the GPU during the timed loops, sampled by a CHILD process (tools/power_sampler.py: sysfs hwmon
+    of every amdgpu card, ~4 Hz; it touches no GPU API).  The child is started before this process initialises the GPU (a process that
+    has must not fork + exec on the pool).  The card of this job = the one whose power rises most from the seconds before the loops to
+    the timed window."""
+
+    def __init__(self):
+        import tempfile
+
+        self.dir = tempfile.mkdtemp(prefix="tamf_power_")
+        self.out, self.stop = os.path.join(self.dir, "samples.txt"), os.path.join(self.dir, "stop")
+        self.t_start = time.time()
+        try:
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), self.out, self.stop],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except OSError:
+            self.proc = None
+
+    def finish(self, t0, t1):
+        """-> dict for the bench line (or None): mean watts / sclk of this job's card over [t0, t1]"""
+        if self.proc is None:
+            return None
+        open(self.stop, "w").close()
+        try:
+            self.proc.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+        try:
+            rows = [list(map(float, l.split())) for l in open(self.out) if l.strip() and l[0] != "#"]
+        except (OSError, ValueError):
+            return None
+        rows = [r for r in rows if len(r) >= 3 and len(r) % 2 == 1]
+        if not rows:
+            return None
+        ncard = (len(rows[0]) - 1) // 2
+
+        def mean(k, a, b, col):
+            xs = [r[1 + 2 * k + col] for r in rows if a <= r[0] <= b and len(r) == 1 + 2 * ncard and r[1 + 2 * k + col] == r[1 + 2 * k + col]]
+            return sum(xs) / len(xs) if xs else None, len(xs)
+
+        best = None
+        for k in range(ncard):
+            w, n = mean(k, t0 + 0.5, t1 - 0.2, 0)
+            pre, _ = mean(k, self.t_start, self.t_start + 3.0, 0)
+            if w is None:
+                continue
+            rise = w - (pre if pre is not None else 0.0)
+            if best is None or rise > best[0]:
+                best = (rise, k, w, n, pre)
+        if best is None:
+            return None
+        _, k, w, n, pre = best
+        mhz, _ = mean(k, t0 + 0.5, t1 - 0.2, 1)
+        return {"watts": w, "sclk_mhz": mhz, "samples": n, "card_column": k, "cards_sampled": ncard, "watts_before_the_run": pre,
+                "what": "mean package power / shader clock of this job's GPU over the timed loops (sysfs hwmon, sampled by tools/power_sampler.py)"}
+
+
+def power_model(dtype, power, ms_per_ddpm_step):
+    """roofline.power_model: the committed energy model of one DDPM step (profiles/rNN/energy_model.json: joules per MFMA / byte /
+    VALU instruction from single-resource microbenchmarks x the step's resource counts, tools/energy_model.py) beside the power this
+    run drew.  predicted_ms = modelled dynamic joules / (measured watts - idle watts).  None when there is no model for the dtype."""
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted((d for d in os.listdir(pdir) if d.startswith("r")), reverse=True) if os.path.isdir(pdir) else []:
+        rel = os.path.join("profiles", rnd, "energy_model.json")
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                m = json.load(f)
+            mm = m["modes"][dtype]
+        except (OSError, ValueError, KeyError):
+            continue
+        e = mm["joules_model"]
+        jb = e.get("fabric_read", 0.0) + e.get("fabric_write", 0.0) + e.get("l2_to_lds", 0.0) + e.get("lds_fragment_reads", 0.0)
+        out = {"source": rel, "workload": "B=64 T=196 arch_mdm_l", "joules_mfma": e.get("mfma"), "joules_bytes": jb, "joules_valu": e.get("valu"),
+               "joules_dynamic_modelled": mm["joules_dynamic_model"], "idle_watts": m["idle_watts"], "cap_watts": m["cap_watts"],
+               "model_run": {"measured_ms": mm["measured_ms"], "measured_watts": mm["measured_watts"], "predicted_ms": mm["predicted_ms_at_measured_power"]}}
+        if power and power.get("watts"):
+            w = power["watts"]
+            out.update({"measured_ms": ms_per_ddpm_step, "measured_watts": w, "measured_joules": w * ms_per_ddpm_step * 1e-3,
+                        "joules_idle": m["idle_watts"] * ms_per_ddpm_step * 1e-3,
+                        "predicted_ms": mm["joules_dynamic_model"] / max(1.0, w - m["idle_watts"]) * 1e3})
+        return out
+    return None
+
+
 def checks_ok(finite_by, range_flags, check):
     """The line's `check_ok`: every reported dtype sampled finite values, no fp16 range flag was raised during the timed loops,
     and every in-run oracle comparison is inside its per-dtype tolerance (NaN fails).  bench.py exits 3 when this is False."""
@@ -287,6 +371,7 @@ def parse_args(argv):
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not start the power / clock sampler child")
     ap.add_argument("--check-clips", type=int, default=2, help="clips of the in-run oracle check (0 = off)")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile of one step here (json)")
     ap.add_argument("--also", default=None,
@@ -315,6 +400,11 @@ def main(argv=None, sampler_factory=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become the launcher (before any GPU call in this process)
         raise SystemExit(spawn_ranks(args.gpus, argv))
+
+    # power / clock sampler child: started BEFORE this process touches the GPU (rank 0 of a real run only)
+    ptrace = None
+    if int(os.environ.get("RANK", "0")) == 0 and not args.sampler and not args.no_power:
+        ptrace = PowerTrace()
 
     import numpy as np  # noqa: F401
     import torch
@@ -389,10 +479,12 @@ def main(argv=None, sampler_factory=None):
         one_loop(1000 + w)
     barrier()
     t0 = time.perf_counter()
+    wall0 = time.time()
     for k in range(args.steps):
         res = one_loop(k)
     barrier()
     elapsed = time.perf_counter() - t0
+    power = ptrace.finish(wall0, time.time()) if ptrace is not None else None
     if world > 1:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -593,6 +685,18 @@ def main(argv=None, sampler_factory=None):
                 "kernel": fr.get("kernel"), "achieved": fr.get("achieved"), "peak": fr.get("peak"), "frac": fr.get("frac"),
                 "attention_frac": (fr.get("attention") or {}).get("frac"),
                 "what": "the same workload in the reference's own arithmetic (exact fp32 MFMA products, fp32 accumulate)"}
+        if power is not None:
+            power["joules_per_ddpm_step"] = power["watts"] * line["ms_per_ddpm_step"] * 1e-3 / world if power.get("watts") else None
+            line["power"] = power
+        if roofline is not None and world == 1 and B == 64 and T == 196 and args.arch == "arch_mdm_l":
+            pmod = power_model(args.dtype, power, line["ms_per_ddpm_step"])
+            if pmod is not None:
+                roofline["power_model"] = pmod
+                # the clock was pulled below its maximum by the power management during the timed loops: the step is energy-bound
+                if power and power.get("sclk_mhz") and power["sclk_mhz"] < 2350.0:
+                    roofline["bound"] = "power"
+                    roofline["bound_note"] = ("shader clock %.0f MHz < 2400 at %.0f W during the timed loops: the power management, not the MFMA issue rate, "
+                                              "sets the step time; frac stays achieved / nominal MFMA peak" % (power["sclk_mhz"], power["watts"]))
         if check:
             line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
                              "what": f"one denoiser evaluation (t={N // 2}) of the first "

@@ -982,6 +982,25 @@ __global__ __launch_bounds__(WGM* WGN * 64, (GemmOcc<BM, BN, WGM * WGN>::WAVES_P
   const int bid = blockIdx.x;
   if (SPLIT == 1 && ga.n_tiles > 0) {
     const int G = gridDim.x;
+    const int ntm = ga.n_tiles / ntn;
+#ifndef TAMF_PERSIST_XCD42  // (A/B builds: 1 = on.  Measured in round 4, profiles/r04/qkv_xcd42_c11.txt: FETCH 119 -> 95.5 MB per QKV launch, but the
+#define TAMF_PERSIST_XCD42 0  //  launch 61.8 - 63.2 -> 63.2 - 63.5 us (f16x3), 29.6 -> 30.8 us (bf16), whole step +0.4 %: off)
+#endif
+    if (TAMF_PERSIST_XCD42 && (ga.krot & 0x10000) && (G & 7) == 0 && (ntm & 3) == 0 && (ntn & 1) == 0 && ntm * ntn == ga.n_tiles) {
+      // 4 x 2 arrangement of the XCDs over the tile grid, persistent form (round 4 experiment; QKV: 104 x 12 tiles on 512 workgroups):
+      // XCD x owns the row panels p = rq (mod 4), rq = x / 2, and the column half x % 2, and keeps them over all its rounds - its L2
+      // then holds HALF of W (1.55 MB of the 4 MB L2; in the round-robin order every L2 pulls all 3.1 MB of W again in each of the
+      // 2.44 rounds, its output stores having evicted them: that, not a re-fetched A panel, is the 108.7 MB the round-3 counters
+      // showed) and an A panel is fetched by the two XCDs of its row quarter.  Same tiles, same K order per tile: the same bits.
+      const int x = bid & 7, slot = bid >> 3, S = G >> 3;  // S workgroup slots per XCD
+      const int rq = x >> 1, ch = x & 1, C = ntn >> 1, nloc = (ntm >> 2) * C;  // tiles of this XCD
+      for (int j = slot; j < nloc; j += S) {
+        const int mb = 4 * (j / C) + rq, nbk = ch * C + j % C;
+        gemm_tile<Op, BM, BN, WGM, WGN, Epi>(ga, epi, mb * BM, nbk * BN, mb * ntn + nbk, bid, smem);
+        __syncthreads();
+      }
+      return;
+    }
     for (int base = 0; base < ga.n_tiles; base += G) {
       const int cnt = ga.n_tiles - base < G ? ga.n_tiles - base : G;
       if (bid < cnt) {

@@ -33,7 +33,7 @@
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
 
-#ifndef TAMF_RB_ABL  // (measurement builds, tools/ab_build.sh: 1 = no activation requests in the K loop, 2 = no weight loads, 3 = neither, 4 = activation requests re-read the first K tiles)
+#ifndef TAMF_RB_ABL  // (measurement builds, tools/ab_build.sh: 1 = no activation requests in the K loop, 2 = no weight loads, 3 = neither, 4 = activation requests re-read the first K tiles, 5 = weight loads re-read the first four K tiles)
 #define TAMF_RB_ABL 0
 #endif
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_ln_kernel(const RowblockArgs<
   int4 wq[2][4][2];
   const int kt_last = KT - 1;
   auto ka_of = [&](int k) { return TAMF_RB_ABL == 4 ? (k & 7) : (k < kt_last ? k : kt_last); };
-  auto kw_of = [&](int k) { return k < kt_last ? k : kt_last; };
+  auto kw_of = [&](int k) { return TAMF_RB_ABL == 5 ? (k & 3) : (k < kt_last ? k : kt_last); };  // (5: the weight loads re-read the first four K tiles - L2 hits)
   constexpr int WAITN = (TAMF_RB_ABL & 1) && TAMF_RB_ABL != 4 ? 0 : 1;
   if (wave < 4) {
     // ---- early waves.  Prologue: pieces of K tiles 0 .. DA - 2, W(0), piece DA - 1; interval k: fragments of k, [W(k + 1), piece k + DA], MFMAs of k

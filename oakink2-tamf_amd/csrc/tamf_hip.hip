@@ -239,7 +239,8 @@ static int g_krot = -1;
 // 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too,
 // 512 = streaming attention kernel in the 16-bit modes too, 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds,
-// 2048 = no row-block kernels: the LayerNorm-fused GEMMs on the LDS-staged tiles of rounds 1 - 3 (set by a tuning word whose low 20 bits are 0x7FFFF)
+// 2048 = the LayerNorm-fused GEMMs on the row-block kernel (tamf_gemm_rowblock.h: weights streamed L2 -> registers; measured in round 4, not
+// faster: off by default; set by a tuning word whose low 20 bits are 0x7FFFF)
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -284,7 +285,7 @@ struct GemmLaunch {
     gb.krot = krot_for(BM <= 64 && BN >= 256);
     // wide-N launches (FFN1: 16 column tiles): XCDs in a 4 x 2 arrangement over the tile grid - each L2 then serves half of W
     // instead of all of it (FETCH_SIZE 162 -> 137 MB per launch, time unchanged); with few column tiles it would re-read A
-    if (g_krot < 0 && BM == 128 && ntn >= 8) gb.krot |= 0x10000;
+    if (g_krot < 0 && BM == 128 && ntn >= 8) gb.krot |= 0x10000;  // (also picked up by the persistent grid below: QKV, round 4)
     gb.n_full = tiles;
     int split = 1;
     if constexpr (CAN_SPLIT) {
@@ -434,8 +435,9 @@ static hipError_t rowblock_launch1(const RowblockArgs<Op>& ra, const EpiLN<Op>& 
 }
 template <class Op>
 static bool rowblock_applies(const GemmArgs<Op>& ga, const void* packed) {
-  if (!packed || (g_sel & (1 | 2048)) || ga.N != 512 || (ga.K * Op::EB) % GEMM_BKB != 0) return false;
-  return (ga.K * Op::EB) / GEMM_BKB >= 8;
+  if (!packed || (g_sel & 1) || !(g_sel & 2048) || ga.N != 512 || (ga.K * Op::EB) % GEMM_BKB != 0) return false;
+  const int KT = (ga.K * Op::EB) / GEMM_BKB;
+  return KT >= 8 && !(KT & 1);
 }
 template <class Op>
 static hipError_t rowblock_launch(const GemmArgs<Op>& ga, const void* packed, const EpiLN<Op>& epi, hipStream_t st) {
@@ -773,7 +775,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout, (p + ".self_attn.out_proj.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2, (p + ".linear2.weight").c_str()));
-    if (d == 512) {  // fragment-major copies for the row-block LayerNorm GEMMs
+    if (d == 512 && (g_sel & 2048)) {  // fragment-major copies for the row-block LayerNorm GEMMs (A/B selection, set BEFORE the weights are finalised)
       TRY(pack_rowblock(ctx, &w.Wout, d, st));
       TRY(pack_rowblock(ctx, &w.W2, ff, st));
     }
@@ -1054,9 +1056,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     }
     {
       GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
-      // Round 4: the row-block kernel with LayerNorm inside (tamf_gemm_rowblock.h; d = 512) in every mode.  Where it does not apply
-      // (d < 512, selection bit 2048) - f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes: the fused
-      // LDS-staged 64 x d tile (40 against 25 + 17 us).  Selection bit 16 forces the two-kernel form.
+      // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes: the fused LDS-staged 64 x d tile (40 against
+      // 25 + 17 us).  Selection bit 16 forces the two-kernel form, 2048 the row-block kernel (tamf_gemm_rowblock.h, round 4: measured,
+      // not faster - f16x3 41 against 39 us here, FFN2 112 against 72 + 17 us - DESIGN.md section 6).
       bool on_clip = false;
       const bool rb = rowblock_applies<Op>(ga, w.Wout.packed) && !(g_sel & 16);
       if (!rb && (Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32) {
@@ -1102,8 +1104,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
       // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
       // (split modes: from 50 % of the slots - at 32 clips per GPU 128 clip tiles beat 208 tiles of 128 x 128: 1.645 -> 1.60 ms per step)
-      // Round 4: the row-block kernel (LayerNorm inside, weights streamed L2 -> registers) in every mode where it applies (d = 512);
-      // selection bit 256 forces the two-kernel form, 2048 the kernels of rounds 1 - 3.
+      // (selection bit 2048: the row-block kernel, LayerNorm inside, weights streamed L2 -> registers - A/B partner, see out-proj above)
       int clip2 = 0;  // 1 = whole-clip tiles, 2 = row-part tiles
       const bool rb = rowblock_applies<Op>(ga, w.W2.packed) && !(g_sel & 256);
       if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
@@ -1791,7 +1792,7 @@ extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..30: kernel-selection overrides (g_sel).
   // The words are process-global and a captured loop graph has the selection of its capture time baked in, so every live
   // context's graph is retired here: the next tamf_sample_loop re-captures with the new selection (same as tamf_denoise).
-  // (selection bit 2048 - no row-block kernels - has no room above bit 30: it is "low 20 bits = 0x7FFFF", i.e. all ones but bit 19)
+  // (selection bit 2048 - the row-block kernels - has no room above bit 30: it is "low 20 bits = 0x7FFFF", i.e. all ones but bit 19)
   int sel = krot >= 0 ? (krot >> 20) & 0x7FF : 0;
   const int low = krot & 0xFFFFF;
   int rot = -1;

@@ -389,3 +389,32 @@ def test_gemm_clip_tiles_exact_integers_t160(prec, clips):
     got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), 0).cpu()
     ref = (a.long() @ w.long().t() + b.long()).float()
     assert torch.equal(got, ref), (prec, clips, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,T", [(64, 196), (32, 196), (48, 160)])
+def test_rowblock_ln_kernels_give_the_same_bits(full, full160, prec, B, T):
+    """The row-block LayerNorm GEMMs of round 4 (csrc/tamf_gemm_rowblock.h: weights streamed L2 -> registers from a fragment-major
+    copy, early / late waves, LayerNorm sums in the ln_row_sum512 tree) are an A/B selection (tuning word 0x7FFFF, set before the weights
+    are finalised; not faster, so off by default): same bits as the default kernels at 64 / 48 / 32 rows per workgroup."""
+    from oakink2_tamf_amd.hip_backend import lib
+
+    fx = full if T == T_FULL else full160
+    cond, x, t = _sub(fx["cond"], slice(0, B)), fx["x"][:B], fx["t"][:B]
+    ctx = _make_ctx(fx["arch"], fx["sd"], B, T, prec)
+    _set_cond(ctx, cond)
+    ref = ctx.denoise(x, t).cpu()
+    n_default = ctx.step_kernel_count
+    ctx.close()
+    try:
+        lib().tamf_set_gemm_tuning(0x7FFFF)
+        ctx = _make_ctx(fx["arch"], fx["sd"], B, T, prec)
+        _set_cond(ctx, cond)
+        got = ctx.denoise(x, t).cpu()
+        n_rb = ctx.step_kernel_count
+        ctx.close()
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+    assert torch.equal(got, ref), (prec, B, T, float((got - ref).abs().max()))
+    if prec in ("f16x3", "bf16x3"):  # (the two-kernel FFN2 of the split modes' default path disappears: proof that the other kernels ran)
+        assert n_rb < n_default, (n_rb, n_default)

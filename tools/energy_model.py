@@ -105,6 +105,15 @@ def fabric(mode):
     return None, None, None
 
 
+def pmc_totals(mode):
+    """measured instruction counts of one step (tools/pmc_step_totals.sh), newest round first; None when absent"""
+    for rnd in ("r04",):
+        p = os.path.join("profiles", rnd, f"pmc_step_totals_{mode}.json")
+        if os.path.exists(p):
+            return json.load(open(p))["per_step"], p
+    return None, None
+
+
 cap = 1400.0
 print()
 out = {"idle_watts": idle, "cap_watts": cap, "joules_per_unit_pJ": {k: v * 1e12 for k, v in jpu.items()}, "modes": {}}
@@ -124,6 +133,9 @@ for mode, mf_case in (("f16x3", "mfma_f16_hilo"), ("bf16x3", "mfma_bf16_hilo"), 
         "l2_to_lds": c["lds_stage"] * jpu["dma_l2_to_lds"],
         "lds_fragment_reads": c["lds_read"] * jpu["lds_read_b128"],
     }
+    pm, pm_src = pmc_totals(mode)
+    if pm:  # non-MFMA vector instructions (wave level), counted by the hardware; priced with the fma loop's joules per instruction
+        e["valu"] = max(0.0, pm["SQ_INSTS_VALU"] - pm["SQ_INSTS_MFMA"]) * jpu["valu_fma"]
     dyn = sum(e.values())
     e_meas = meas["watts"] * t_meas
     t_pred_cap = dyn / (cap - idle)                       # if the step ran at the cap the whole time
@@ -131,7 +143,8 @@ for mode, mf_case in (("f16x3", "mfma_f16_hilo"), ("bf16x3", "mfma_bf16_hilo"), 
     out["modes"][mode] = {"measured_ms": t_meas * 1e3, "measured_watts": meas["watts"], "measured_sclk_mhz": meas["mhz"],
                           "measured_joules_per_step": e_meas, "joules_idle": idle * t_meas, "joules_dynamic_measured": e_meas - idle * t_meas,
                           "joules_model": e, "joules_dynamic_model": dyn, "predicted_ms_at_cap": t_pred_cap * 1e3,
-                          "predicted_ms_at_measured_power": t_pred_same_power * 1e3, "counts": c, "fabric_read_bytes": rd, "fabric_write_bytes": wr, "fabric_source": src}
+                          "predicted_ms_at_measured_power": t_pred_same_power * 1e3, "counts": c, "fabric_read_bytes": rd, "fabric_write_bytes": wr, "fabric_source": src, "pmc_source": pm_src,
+                          "pmc_mfma_instructions": pm["SQ_INSTS_MFMA"] if pm else None}
     print(f"{mode}: measured {t_meas * 1e3:.3f} ms/step at {meas['watts']:.0f} W ({meas['mhz']:.0f} MHz) = {e_meas:.3f} J/step, of which idle {idle * t_meas:.3f} J, dynamic {e_meas - idle * t_meas:.3f} J")
     print("   model: " + "  ".join(f"{k} {v:.3f} J" for k, v in e.items()) + f"  = {dyn:.3f} J dynamic")
     print(f"   predicted step: {t_pred_same_power * 1e3:.3f} ms at the loop's own power, {t_pred_cap * 1e3:.3f} ms at the {cap:.0f} W cap   (measured {t_meas * 1e3:.3f} ms; model / measured dynamic energy = {dyn / (e_meas - idle * t_meas):.2f})")
