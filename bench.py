@@ -403,7 +403,10 @@ def main(argv=None, sampler_factory=None):
 
     # power / clock sampler child: started BEFORE this process touches the GPU (rank 0 of a real run only)
     ptrace = None
-    if int(os.environ.get("RANK", "0")) == 0 and not args.sampler and not args.no_power:
+    # (never under a profiler: rocprofv3's preloaded library has initialised the GPU before this line, and a process that has must
+    #  not fork + exec on the pool - tools/*.sh pass --no-power as well)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if int(os.environ.get("RANK", "0")) == 0 and not args.sampler and not args.no_power and not under_profiler:
         ptrace = PowerTrace()
 
     import numpy as np  # noqa: F401

@@ -11,7 +11,7 @@ i=0
 for grp in "${G[@]}"; do
   i=$((i+1))
   rm -rf gpurun_out/gpmc
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/gpmc -o r -- python3 bench.py --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also "" --fp32-loops 0 --check-clips 0 --dtype $dt > gpurun_out/gpmc.log 2>&1
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/gpmc -o r -- python3 bench.py --no-power --steps 1 --warmup 0 --ddpm-steps 10 --no-cpu-baseline --also "" --fp32-loops 0 --check-clips 0 --dtype $dt > gpurun_out/gpmc.log 2>&1
   python3 - $i <<'PY'
 import csv, glob, collections, json, sys
 f = glob.glob("gpurun_out/gpmc/**/*counter_collection.csv", recursive=True)
