@@ -126,9 +126,13 @@ class TamfContext:
     """One library context = one (model, device, precision, max batch, max frames)."""
 
     def __init__(self, arch: Mapping[str, int], max_batch: int, max_frames: int, precision: str = DEFAULT_PRECISION,
-                 device=None, kind: str = "G"):
+                 device=None, kind: str = "G", range_check: bool = False):
+        """range_check=True: `denoise`, `sample_loop` and `refine` read this context's status word after the call (one stream
+        synchronisation) and raise TamfRangeError when an activation left the fp16 range (f16x3 only).  The drop-in modules do
+        their own check - with an f32 fallback - and leave this off; a raw context has no fallback."""
         self.device = require_gpu(device)
         self.precision = precision
+        self.range_check = bool(range_check) and precision == "f16x3"
         self.kind = kind
         a = _Arch(
             input_dim=int(arch.get("input_dim", 99)),
@@ -229,6 +233,7 @@ class TamfContext:
         with torch.cuda.device(dev):
             _check(lib().tamf_denoise(self._h, c_void_p(xd.data_ptr()), c_void_p(td.data_ptr()), c_void_p(out.data_ptr()),
                                       c_void_p(_stream_ptr(dev))), self._h)
+        self._raise_on_range()
         return out
 
     def ddpm_step(self, x_t: torch.Tensor, x0: torch.Tensor, t: int, noise: Optional[torch.Tensor]) -> torch.Tensor:
@@ -261,7 +266,13 @@ class TamfContext:
                                           c_void_p(dmp.data_ptr() if dmp is not None else 0), 1 if use_graph else 0,
                                           c_void_p(_stream_ptr(dev))), self._h)
         self._keep_loop = [nz, dmp]
+        self._raise_on_range()
         return (out, dmp) if dump else out
+
+    def _raise_on_range(self):
+        if self.range_check and (self.status_flags(clear=True) & STATUS_F16_RANGE):
+            raise TamfRangeError("f16x3: an activation beyond +-65504 was stored as a split-fp16 operand by this context; the result may "
+                                 "differ from the reference's fp32 arithmetic (use precision='f32' or 'bf16x3')")
 
     def status_flags(self, clear: bool = True) -> int:
         """Sticky status bits of THIS context (STATUS_F16_RANGE: one of its launches stored an activation beyond +-65504 as a
@@ -282,6 +293,7 @@ class TamfContext:
         with torch.cuda.device(dev):
             _check(lib().tamf_refine(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()),
                                      c_void_p(_stream_ptr(dev))), self._h)
+        self._raise_on_range()
         return out
 
     def loop_stats(self):

@@ -217,6 +217,19 @@ def test_f16x3_activation_overflow_raises_the_status_flag():
     assert ctx.status_flags() & STATUS_F16_RANGE  # sticky until cleared
     assert ctx.status_flags() == 0
     ctx.close()
+    # a raw context built with range_check=True raises by itself (no fallback at this level)
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfRangeError
+    from test_hip_forward import _arch_dict
+
+    ctx = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3", range_check=True)
+    ctx.load_state_dict(big)
+    tab = O.make_tables(1000, "cosine")
+    ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+    _set_cond(ctx, cond)
+    with pytest.raises(TamfRangeError):
+        ctx.denoise(x, t)
+    assert ctx.status_flags() == 0  # read and cleared by the raise
+    ctx.close()
     # the same weights in f32: correct, and no flag
     ctx = _ctx(arch, big, 2, 16, "f32")
     _set_cond(ctx, cond)
