@@ -1061,11 +1061,16 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // not faster - f16x3 41 against 39 us here, FFN2 112 against 72 + 17 us - DESIGN.md section 6).
       bool on_clip = false;
       const bool rb = rowblock_applies<Op>(ga, w.Wout.packed) && !(g_sel & 16);
-      if (!rb && (Op::PREC == 0 || (g_sel & 16)) && !(g_sel & 2) && ctx->tmp32) {
+      // Round 4: at 32 clips per GPU (whole-clip tiles on at most half of the CUs) the split modes take the two-kernel form too, on the
+      // 7 + 6 / 6 + 5 row-part tiles: 15.0 + 8.4 against 28.0 us for the fused 32-row tile (f16x3; bf16 9.0 + 6.7 against 15.6: stays fused)
+      if (!rb && !(g_sel & 2) && ctx->tmp32) {
         TAMF_CLIP_NSUB(Sp, {
-          if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d)) {
+          const bool parts = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, d);  // (at most half of the CUs would get a whole clip: 32 clips per GPU)
+          const bool two_kernel = Op::PREC == 0 || (g_sel & 16) || (Op::SPLIT && parts);
+          if (two_kernel && (parts || ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d))) {
             EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
-            HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
+            if (parts) HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
+            else HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
             mark("gemm_outproj", BS * 2.0 * dd * dd);
             launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
             mark("outproj_residual_ln", 0.0);
@@ -1109,8 +1114,8 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       const bool rb = rowblock_applies<Op>(ga, w.W2.packed) && !(g_sel & 256);
       if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
         TAMF_CLIP_NSUB(Sp, {
-          if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74))
-            clip2 = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff) ? 2 : 1;
+          if (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff)) clip2 = 2;  // (f32 at 32 clips per GPU ran the fused tile before round 4: 236 us)
+          else if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74)) clip2 = 1;
         })
       }
       if (!rb && (Op::SPLIT || clip2) && ctx->tmp32) {
