@@ -1060,13 +1060,16 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // 25 + 17 us).  Selection bit 16 forces the two-kernel form, 2048 the row-block kernel (tamf_gemm_rowblock.h, round 4: measured,
       // not faster - f16x3 41 against 39 us here, FFN2 112 against 72 + 17 us - DESIGN.md section 6).
       bool on_clip = false;
+      const bool ln_underfilled = ((M + 63) / 64) * 100 < (g_wg_slots / 2) * 70;  // the fused 64 x d LayerNorm tile fills < 70 % of the CUs
       const bool rb = rowblock_applies<Op>(ga, w.Wout.packed) && !(g_sel & 16);
       // Round 4: at 32 clips per GPU (whole-clip tiles on at most half of the CUs) the split modes take the two-kernel form too, on the
       // 7 + 6 / 6 + 5 row-part tiles: 15.0 + 8.4 against 28.0 us for the fused 32-row tile (f16x3; bf16 9.0 + 6.7 against 15.6: stays fused)
       if (!rb && !(g_sel & 2) && ctx->tmp32) {
         TAMF_CLIP_NSUB(Sp, {
           const bool parts = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, d);  // (at most half of the CUs would get a whole clip: 32 clips per GPU)
-          const bool two_kernel = Op::PREC == 0 || (g_sel & 16) || (Op::SPLIT && parts);
+          // ... and whenever the fused 64-row tile would leave more than 30 % of the CUs idle in its single round (T = 160 at 64 clips:
+          // 168 blocks on 256 CUs; whole-clip tiles of 11 row tiles are exactly one round): 17.8 + 12.9 against 33.7 us (f16x3)
+          const bool two_kernel = Op::PREC == 0 || (g_sel & 16) || (Op::SPLIT && (parts || ln_underfilled));
           if (two_kernel && (parts || ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d))) {
             EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
             if (parts) HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
@@ -1112,7 +1115,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
       // (selection bit 2048: the row-block kernel, LayerNorm inside, weights streamed L2 -> registers - A/B partner, see out-proj above)
       int clip2 = 0;  // 1 = whole-clip tiles, 2 = row-part tiles
       const bool rb = rowblock_applies<Op>(ga, w.W2.packed) && !(g_sel & 256);
-      if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256)) && !(g_sel & 2)) {
+      // (bf16: the fused tile - unless it would leave more than 30 % of the CUs idle (T = 160 at 64 clips): 26.2 + 11.0 against 41.7 us)
+      const bool ln_underfilled = ((M + 63) / 64) * 100 < (g_wg_slots / 2) * 70;
+      if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256) || ln_underfilled) && !(g_sel & 2)) {
         TAMF_CLIP_NSUB(Sp, {
           if (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff)) clip2 = 2;  // (f32 at 32 clips per GPU ran the fused tile before round 4: 236 us)
           else if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74)) clip2 = 1;

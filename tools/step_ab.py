@@ -1,5 +1,5 @@
 """GPU: per-kernel HIP-event profile of one denoiser step under different GEMM-selection bits (tamf_set_gemm_tuning):
-   python tools/step_ab.py [prec] [B] [variants, comma list of ints; -1 = default]"""
+   python tools/step_ab.py [prec] [B] [variants, comma list of ints; -1 = default] [T]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oakink2-tamf_amd")]
@@ -11,7 +11,7 @@ from oracle import mdm_oracle as O
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 variants = [int(v, 0) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [-1]
-T = 196
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 196
 arch = dict(latent_dim=512, ff_size=2048, num_layers=8, num_heads=4)
 sd = O.det_state_dict(O.ARCH_MDM_L, tag="bench/w")
 tab = O.make_tables(1000, "cosine")
@@ -32,5 +32,5 @@ for v in variants:
             a = agg.setdefault(n, [0.0, 0])
             a[0] += ms; a[1] += 1
     tot = sum(a[0] for a in agg.values()) / 5
-    print(f"{prec} B={B} variant {v:#x}: step {tot*1e3:.0f} us | " + " ".join(f"{n}={a[0]/a[1]*1e3:.1f}" for n, a in agg.items()), flush=True)
+    print(f"{prec} B={B} T={T} variant {v:#x}: step {tot*1e3:.0f} us | " + " ".join(f"{n}={a[0]/a[1]*1e3:.1f}" for n, a in agg.items()), flush=True)
 lib().tamf_set_gemm_tuning(-1)
