@@ -117,6 +117,23 @@ class PowerTrace:
                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         except OSError:
             self.proc = None
+        import atexit
+
+        atexit.register(self.cleanup)  # (a bench that dies early must not leave its sampler behind; the sampler also ends by itself after 30 min)
+
+    def cleanup(self):
+        import shutil
+
+        try:
+            open(self.stop, "w").close()
+        except OSError:
+            pass
+        if self.proc is not None and self.proc.poll() is None:
+            try:
+                self.proc.wait(timeout=3)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+        shutil.rmtree(self.dir, ignore_errors=True)
 
     def finish(self, t0, t1):
         """-> dict for the bench line (or None): mean watts / sclk of this job's card over [t0, t1]"""
@@ -131,6 +148,12 @@ class PowerTrace:
             rows = [list(map(float, l.split())) for l in open(self.out) if l.strip() and l[0] != "#"]
         except (OSError, ValueError):
             return None
+        return self.summarise(rows, self.t_start, t0, t1)
+
+    @staticmethod
+    def summarise(rows, t_start, t0, t1):
+        """rows: [t, watts card 0, sclk card 0, watts card 1, ...] (tools/power_sampler.py).  The card of this job = the one whose mean
+        power rises most from the first 3 s after t_start (this process was still importing) to the timed window [t0, t1]."""
         rows = [r for r in rows if len(r) >= 3 and len(r) % 2 == 1]
         if not rows:
             return None
@@ -138,12 +161,12 @@ class PowerTrace:
 
         def mean(k, a, b, col):
             xs = [r[1 + 2 * k + col] for r in rows if a <= r[0] <= b and len(r) == 1 + 2 * ncard and r[1 + 2 * k + col] == r[1 + 2 * k + col]]
-            return sum(xs) / len(xs) if xs else None, len(xs)
+            return (sum(xs) / len(xs) if xs else None), len(xs)
 
         best = None
         for k in range(ncard):
             w, n = mean(k, t0 + 0.5, t1 - 0.2, 0)
-            pre, _ = mean(k, self.t_start, self.t_start + 3.0, 0)
+            pre, _ = mean(k, t_start, t_start + 3.0, 0)
             if w is None:
                 continue
             rise = w - (pre if pre is not None else 0.0)

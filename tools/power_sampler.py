@@ -32,7 +32,8 @@ def sysfs_cards():
 cards = sysfs_cards()
 with open(out, "w") as f:
     f.write(f"# source: {'sysfs: ' + ' '.join(c[0] for c in cards) if cards else 'rocm-smi GPU[0]'}\n")
-    while not os.path.exists(stop):
+    t_end = time.time() + 1800.0  # (never outlives its parent by more than this)
+    while not os.path.exists(stop) and time.time() < t_end:
         t = time.time()
         vals = []
         try:
