@@ -194,6 +194,9 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
       (void)std::frexp(mx, &e);  // mx = m 2^e, m in [0.5, 1)
       wexp = std::min(120, std::max(-120, 15 - e));
     }
+#ifdef TAMF_NO_PRESCALE  // (A/B builds: the unscaled split of rounds 2 - 3; weights beyond 65504 then turn into inf)
+    wexp = 0;
+#endif
     out->inv_scale = std::ldexp(1.0f, -wexp);
   }
   if (prec == TAMF_PREC_F32) {
