@@ -135,8 +135,9 @@ class PowerTrace:
                 self.proc.kill()
         shutil.rmtree(self.dir, ignore_errors=True)
 
-    def finish(self, t0, t1):
-        """-> dict for the bench line (or None): mean watts / sclk of this job's card over [t0, t1]"""
+    def finish(self, t0, t1, pci=None):
+        """-> dict for the bench line (or None): mean watts / sclk of this job's card over [t0, t1].  pci = the PCI address of this
+        process's device ("0000:bb:dd.f"): matched against the sampler's header; without a match the card is guessed from the power rise."""
         if self.proc is None:
             return None
         open(self.stop, "w").close()
@@ -144,16 +145,24 @@ class PowerTrace:
             self.proc.wait(timeout=5)
         except subprocess.TimeoutExpired:
             self.proc.kill()
+        column = None
         try:
-            rows = [list(map(float, l.split())) for l in open(self.out) if l.strip() and l[0] != "#"]
+            lines = open(self.out).read().split("\n")
+            rows = [list(map(float, l.split())) for l in lines if l.strip() and l[0] != "#"]
+            for l in lines:
+                if l.startswith("# pci:") and pci:
+                    addrs = [a.lower() for a in l.split()[2:]]
+                    if pci.lower() in addrs:
+                        column = addrs.index(pci.lower())
         except (OSError, ValueError):
             return None
-        return self.summarise(rows, self.t_start, t0, t1)
+        return self.summarise(rows, self.t_start, t0, t1, column)
 
     @staticmethod
-    def summarise(rows, t_start, t0, t1):
-        """rows: [t, watts card 0, sclk card 0, watts card 1, ...] (tools/power_sampler.py).  The card of this job = the one whose mean
-        power rises most from the first 3 s after t_start (this process was still importing) to the timed window [t0, t1]."""
+    def summarise(rows, t_start, t0, t1, column=None):
+        """rows: [t, watts card 0, sclk card 0, watts card 1, ...] (tools/power_sampler.py).  The card of this job = `column` when the
+        caller could match its device's PCI address; else the one whose mean power rises most from the first 3 s after t_start (this
+        process was still importing) to the timed window [t0, t1] - a guess that another job starting on a neighbouring card can fool."""
         rows = [r for r in rows if len(r) >= 3 and len(r) % 2 == 1]
         if not rows:
             return None
@@ -164,7 +173,7 @@ class PowerTrace:
             return (sum(xs) / len(xs) if xs else None), len(xs)
 
         best = None
-        for k in range(ncard):
+        for k in (range(ncard) if column is None or column >= ncard else [column]):
             w, n = mean(k, t0 + 0.5, t1 - 0.2, 0)
             pre, _ = mean(k, t_start, t_start + 3.0, 0)
             if w is None:
@@ -176,7 +185,8 @@ class PowerTrace:
             return None
         _, k, w, n, pre = best
         mhz, _ = mean(k, t0 + 0.5, t1 - 0.2, 1)
-        return {"watts": w, "sclk_mhz": mhz, "samples": n, "card_column": k, "cards_sampled": ncard, "watts_before_the_run": pre,
+        return {"watts": w, "sclk_mhz": mhz, "samples": n, "card_column": k, "card_matched_by": "pci address" if column is not None and column < ncard else "power rise (guess)",
+                "cards_sampled": ncard, "watts_before_the_run": pre,
                 "what": "mean package power / shader clock of this job's GPU over the timed loops (sysfs hwmon, sampled by tools/power_sampler.py)"}
 
 
@@ -510,7 +520,18 @@ def main(argv=None, sampler_factory=None):
         res = one_loop(k)
     barrier()
     elapsed = time.perf_counter() - t0
-    power = ptrace.finish(wall0, time.time()) if ptrace is not None else None
+    power = None
+    if ptrace is not None:
+        pci = None
+        if dev.type == "cuda":
+            try:
+                pr = torch.cuda.get_device_properties(dev)
+                pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            except (AttributeError, RuntimeError):
+                pci = None
+        power = ptrace.finish(wall0, time.time(), pci)
+        if power is not None:
+            power["pci"] = pci
     if world > 1:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)

@@ -19,6 +19,10 @@ def test_power_summary_picks_the_card_whose_power_rises():
     assert p["card_column"] == 2 and p["cards_sampled"] == 3
     assert abs(p["watts"] - 1300.0) < 1e-6 and abs(p["sclk_mhz"] - 2000.0) < 1e-6 and p["samples"] > 30
     assert abs(p["watts_before_the_run"] - 280.0) < 1e-6
+    assert p["card_matched_by"].startswith("power rise")
+    # with the device's PCI address matched to a column, the busy neighbour cannot be picked even if IT rises more
+    q = bench.PowerTrace.summarise(rows, 1000.0, 1010.0, 1020.0, column=1)
+    assert q["card_column"] == 1 and abs(q["watts"] - 270.0) < 1e-6 and q["card_matched_by"] == "pci address"
     assert bench.PowerTrace.summarise([], 0, 1, 2) is None
 
 

@@ -136,6 +136,13 @@ for mode, mf_case in (("f16x3", "mfma_f16_hilo"), ("bf16x3", "mfma_bf16_hilo"), 
     pm, pm_src = pmc_totals(mode)
     if pm:  # non-MFMA vector instructions (wave level), counted by the hardware; priced with the fma loop's joules per instruction
         e["valu"] = max(0.0, pm["SQ_INSTS_VALU"] - pm["SQ_INSTS_MFMA"]) * jpu["valu_fma"]
+        if "salu" in jpu and "SQ_INSTS_SALU" in pm:
+            e["salu"] = pm["SQ_INSTS_SALU"] * jpu["salu"]
+    if "mfma_f16_from_lds" in jpu:
+        # MFMAs whose operands change with every instruction (fed from LDS as in a K loop: 20 KiB of fragment reads per 72 MFMAs) cost
+        # more than the register-only loop, which re-uses 8 operand registers: the factor measured on f16 is applied to every mode
+        ref = jpu["mfma_f16_hilo"] + 20 * 1024 / 72.0 * jpu["lds_read_b128"]
+        e["mfma_operand_refresh"] = e["mfma"] * (jpu["mfma_f16_from_lds"] / ref - 1.0)
     dyn = sum(e.values())
     e_meas = meas["watts"] * t_meas
     t_pred_cap = dyn / (cap - idle)                       # if the step ran at the cap the whole time

@@ -52,6 +52,49 @@ __global__ __launch_bounds__(512) void k_mfma(float* out, int iters, int data) {
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (s == 1234.5678f) out[id] = s;
 }
+// ---- MFMAs fed from LDS the way a K loop feeds them: per "K tile" a wave reads 10 row-tile fragments (20 x ds_read_b128) of random split-fp16
+// data and issues 6 x 4 products x 3 MFMAs on them - the operands of consecutive MFMAs change, which a register-only loop never exercises
+__global__ __launch_bounds__(512) void k_mfma_lds(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  for (int i = threadIdx.x; i < 128 * 1024 / 4; i += blockDim.x) {
+    const float v = rnd(i * 7 + blockIdx.x);
+    const _Float16 h = (_Float16)((i & 16) ? v * 4.8828125e-4f : v);  // (hi | lo planes alternate per 64 bytes as in the operand layout)
+    const _Float16 h2 = (_Float16)((i & 16) ? rnd(i * 13 + 5) * 4.8828125e-4f : rnd(i * 13 + 5));
+    ((unsigned*)lds)[i] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f4 acc[6][4];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    const char* base = lds + ((it & 3) * 24 * 1024) + (wave & 1) * 12 * 1024 + lane * 16;  // 4 stages, conflict-free 16 B per lane
+    h8 a[6][2], b[4][2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { a[i][0] = *(const h8*)(base + i * 2048); a[i][1] = *(const h8*)(base + i * 2048 + 1024); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j][0] = *(const h8*)(base + (6 + (j & 1)) * 2048 - (j >> 1) * 1024); b[j][1] = *(const h8*)(base + (j & 3) * 2048 + 1024); }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][1], a[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], a[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], a[i][0], acc[i][j], 0, 0, 0);
+      }
+  }
+  float sum = 0.f;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][3];
+  if (sum == 1234.5678f) out[threadIdx.x] = sum;
+}
+// ---- scalar ALU only
+__global__ __launch_bounds__(512) void k_salu(float* out, int iters) {
+  unsigned a = blockIdx.x, b = 0x9e3779b9u;
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0"
+                 : "+s"(a), "+s"(b));
+  }
+  if (a == 0x12345678u && iters < 0) out[0] = (float)b;
+}
 // ---- VALU only: 8 independent fma chains per lane
 __global__ __launch_bounds__(512) void k_valu(float* out, int iters) {
   const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +206,9 @@ int main(int argc, char** argv) {
   run_case("mfma_bf16_random", secs, mfmas, "MFMA", [&] { hipLaunchKernelGGL(k_mfma<1>, dim3(2 * cus), dim3(512), 0, 0, sink, it_m, 1); });
   run_case("mfma_bf16_hilo", secs, mfmas, "MFMA", [&] { hipLaunchKernelGGL(k_mfma<1>, dim3(2 * cus), dim3(512), 0, 0, sink, it_m, 2); });
   run_case("mfma_f32_random", secs, mfmas, "MFMA", [&] { hipLaunchKernelGGL(k_mfma<2>, dim3(2 * cus), dim3(512), 0, 0, sink, it_m, 1); });
+  hipFuncSetAttribute((const void*)k_mfma_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  run_case("mfma_f16_from_lds", secs, (double)cus * 8 * 1500.0 * 72, "MFMA", [&] { hipLaunchKernelGGL(k_mfma_lds, dim3(cus), dim3(512), 128 * 1024, 0, sink, 1500); });
+  run_case("salu", secs, (double)2 * cus * 8 * 40000.0 * 8, "SALUinst", [&] { hipLaunchKernelGGL(k_salu, dim3(2 * cus), dim3(512), 0, 0, sink, 40000); });
   run_case("valu_fma", secs, (double)2 * cus * 8 * 20000.0 * 8, "VALUinst", [&] { hipLaunchKernelGGL(k_valu, dim3(2 * cus), dim3(512), 0, 0, sink, 20000); });
   run_case("lds_read_b128", secs, (double)cus * 512 * 16 * 8 * 20000.0, "B", [&] { hipLaunchKernelGGL(k_ldsread, dim3(cus), dim3(512), 64 * 1024, 0, sink, 20000); });
   run_case("dma_l2_to_lds", secs, (double)cus * (2 << 20) * 64.0, "B", [&] { hipLaunchKernelGGL(k_dma, dim3(cus), dim3(512), 128 * 1024, 0, big, 0L, 2L << 20, 64, sink); });

@@ -32,6 +32,8 @@ def sysfs_cards():
 cards = sysfs_cards()
 with open(out, "w") as f:
     f.write(f"# source: {'sysfs: ' + ' '.join(c[0] for c in cards) if cards else 'rocm-smi GPU[0]'}\n")
+    # PCI address of every sampled card, in column order: bench.py matches its own device (torch's pci_domain/bus/device ids) against it
+    f.write("# pci: " + " ".join(os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(os.path.dirname(c[0]))))) for c in cards) + "\n")
     t_end = time.time() + 1800.0  # (never outlives its parent by more than this)
     while not os.path.exists(stop) and time.time() < t_end:
         t = time.time()
