@@ -205,7 +205,8 @@ def power_model(dtype, power, ms_per_ddpm_step):
             continue
         e = mm["joules_model"]
         jb = e.get("fabric_read", 0.0) + e.get("fabric_write", 0.0) + e.get("l2_to_lds", 0.0) + e.get("lds_fragment_reads", 0.0)
-        out = {"source": rel, "workload": "B=64 T=196 arch_mdm_l", "joules_mfma": e.get("mfma"), "joules_bytes": jb, "joules_valu": e.get("valu"),
+        out = {"source": rel, "workload": "B=64 T=196 arch_mdm_l", "joules_mfma": e.get("mfma", 0.0) + e.get("mfma_operand_refresh", 0.0), "joules_bytes": jb,
+               "joules_valu": e.get("valu", 0.0) + e.get("salu", 0.0),
                "joules_dynamic_modelled": mm["joules_dynamic_model"], "idle_watts": m["idle_watts"], "cap_watts": m["cap_watts"],
                "model_run": {"measured_ms": mm["measured_ms"], "measured_watts": mm["measured_watts"], "predicted_ms": mm["predicted_ms_at_measured_power"]}}
         if power and power.get("watts"):
@@ -439,12 +440,13 @@ def main(argv=None, sampler_factory=None):
     # (never under a profiler: rocprofv3's preloaded library has initialised the GPU before this line, and a process that has must
     #  not fork + exec on the pool - tools/*.sh pass --no-power as well)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if int(os.environ.get("RANK", "0")) == 0 and not args.sampler and not args.no_power and not under_profiler:
-        ptrace = PowerTrace()
-
     import numpy as np  # noqa: F401
-    import torch
+    import torch  # (importing torch does not initialise the GPU; is_available() / any HIP call does)
     import torch.distributed as dist
+
+    # ... nor from a process that has ALREADY initialised the GPU (bench.main called from a test or a notebook that used the GPU before)
+    if int(os.environ.get("RANK", "0")) == 0 and not args.sampler and not args.no_power and not under_profiler and not torch.cuda.is_initialized():
+        ptrace = PowerTrace()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
