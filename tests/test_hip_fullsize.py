@@ -418,3 +418,52 @@ def test_rowblock_ln_kernels_give_the_same_bits(full, full160, prec, B, T):
     assert torch.equal(got, ref), (prec, B, T, float((got - ref).abs().max()))
     if prec in ("f16x3", "bf16x3"):  # (the two-kernel FFN2 of the split modes' default path disappears: proof that the other kernels ran)
         assert n_rb < n_default, (n_rb, n_default)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_forward_arch_mdm_b64_t160_vs_oracle(prec):
+    """The small architecture (arch_mdm: d = 256, ff = 1024, 4 heads of 64) at the dataset's shape, B = 64, T = 160: the 11-row-tile clip
+    tiles at K = 256 / N = 1024, the 12-key-tile resident-K attention at hd = 64, the 256-column LayerNorm tiles."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM
+    sd = O.det_state_dict(arch, tag="mdm160/w")
+    cond = O.det_cond(B_FULL, T_DS, tag="mdm160/c", arch=arch)
+    g = torch.Generator().manual_seed(161)
+    x = torch.randn(B_FULL, 99, 1, T_DS, generator=g)
+    t = torch.randint(0, 1000, (B_FULL,), generator=g)
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd, arch, x, t, cond)
+    ctx = _make_ctx(arch, sd, B_FULL, T_DS, prec)
+    _set_cond(ctx, cond)
+    out = ctx.denoise(x, t).cpu()
+    err = float((out - ref).abs().max())
+    print(f"arch_mdm forward[{prec}] B=64 T=160: max|err| = {err:.3e}")
+    assert err < FWD_TOL[prec], (prec, err)
+    # a clip alone = the clip in the batch, bit for bit (other kernel selections at B = 1)
+    _set_cond(ctx, _sub(cond, slice(5, 6)))
+    one = ctx.denoise(x[5:6], t[5:6]).cpu()
+    assert torch.equal(one[0], out[5])
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_refine_b64_t160_vs_oracle(prec):
+    """The R trunk (arch_refine) at the dataset's clip length, B = 64, T = 160 (3 prefix tokens: S = 163, Sp = 168)."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_REFINE
+    sd = O.det_state_dict(arch, tag="fullr/w")
+    cond = O.det_cond(B_FULL, T_DS, tag="fullr160/c", arch=arch)
+    g = torch.Generator().manual_seed(31)
+    x_in = torch.randn(B_FULL, T_DS, 99, generator=g)
+    h2o = torch.rand(B_FULL, T_DS, 778, generator=g) * 0.2
+    with torch.no_grad():
+        ref = O.refine_forward(sd, arch, x_in, h2o, cond)
+    ctx = _make_ctx(arch, sd, B_FULL, T_DS, prec)
+    _set_cond(ctx, cond)
+    out = ctx.refine(x_in, h2o).cpu()
+    err = float((out - ref).abs().max())
+    print(f"refine[{prec}] B=64 T=160: max|err| = {err:.3e}")
+    assert err < REFINE_TOL[prec], (prec, err)
+    ctx.close()
