@@ -483,7 +483,7 @@ struct EpiSeqRows {
           }
           const long o = ((long)b * Sp + s) * d + c;
           g_store8(xout + o, v);
-          Op::template store_rc<8>(xop, o, v, am);
+          if (xop) Op::template store_rc<8>(xop, o, v, am);  // (null in f32: the operand matrix IS the fp32 state there)
         }
       }
     }
@@ -584,7 +584,7 @@ struct EpiLN {
       } else {
         *(float2*)op = make_float2(v[0], v[1]);
       }
-      Op::template store_rc<VPL>(xop, (long)gr * BN + c0, v, am);
+      if (xop) Op::template store_rc<VPL>(xop, (long)gr * BN + c0, v, am);
     }
     Op::range_flag(am, ctl.status);
   }
@@ -689,7 +689,7 @@ struct EpiHead {
           }
         }
         g_store8(xs + srow + gn, xn);
-        Op::template store_rc<8>(xs_op, srow + gn, xn, am);
+        if (xs_op) Op::template store_rc<8>(xs_op, srow + gn, xn, am);
       }
     }
     Op::range_flag(am, ctl.status);

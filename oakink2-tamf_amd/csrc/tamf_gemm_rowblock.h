@@ -393,14 +393,14 @@ __global__ __launch_bounds__(512, 2) void rowblock_ln_kernel(const RowblockArgs<
           const long o = (long)gr * N + colb(2 * nql);
           gst16f(epi.xout + o, y[0], y[1], y[2], y[3]);
           gst16f(epi.xout + o + 4, y[4], y[5], y[6], y[7]);
-          Op::template store_rc<8>(epi.xop, o, y, am);
+          if (epi.xop) Op::template store_rc<8>(epi.xop, o, y, am);
         }
       } else {
 #pragma unroll
         for (int jl = 0; jl < 4; ++jl) {
           const long o = (long)gr * N + colb(jl);
           gst16f(epi.xout + o, v[mi][jl][0], v[mi][jl][1], v[mi][jl][2], v[mi][jl][3]);
-          Op::template store_rc<4>(epi.xop, o, v[mi][jl], am);
+          if (epi.xop) Op::template store_rc<4>(epi.xop, o, v[mi][jl], am);
         }
       }
     }

@@ -35,7 +35,7 @@ __global__ void state_in_kernel(const float* __restrict__ x, float* __restrict__
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   float am = 0.f;
-  Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);
+  if (xs_op) Op::template store_rc<8>(xs_op, (long)bt * XK + cg * 8, v, am);  // (null in f32: xs is the operand)
   Op::range_flag(am, status);
 }
 
@@ -120,7 +120,7 @@ __global__ void residual_ln_kernel(const float* __restrict__ c, const float* res
     for (int j = 0; j < VPL; ++j) xout[(long)row * D + c0 + j] = v[j];
   }
   float am = 0.f;
-  Op::template store_rc<VPL>(xop, (long)row * D + c0, v, am);
+  if (xop) Op::template store_rc<VPL>(xop, (long)row * D + c0, v, am);  // (null in f32: xout is the operand)
   Op::range_flag(am, status);
 }
 
