@@ -735,7 +735,8 @@ def main(argv=None, sampler_factory=None):
                 "attention_frac": (fr.get("attention") or {}).get("frac"),
                 "what": "the same workload in the reference's own arithmetic (exact fp32 MFMA products, fp32 accumulate)"}
         if power is not None:
-            power["joules_per_ddpm_step"] = power["watts"] * line["ms_per_ddpm_step"] * 1e-3 / world if power.get("watts") else None
+            # (rank 0's GPU; every rank runs its own clips through the same number of DDPM steps in ms_per_ddpm_step)
+            power["joules_per_ddpm_step_per_gpu"] = power["watts"] * line["ms_per_ddpm_step"] * 1e-3 if power.get("watts") else None
             line["power"] = power
         if roofline is not None and world == 1 and B == 64 and T == 196 and args.arch == "arch_mdm_l":
             pmod = power_model(args.dtype, power, line["ms_per_ddpm_step"])
