@@ -161,29 +161,56 @@ TAMF_DEV ClipSrc clip_src(const ClipGemmArgs<Op>& ga, int b, int n0, int nq, int
   s.hq = e >> 5;
   return s;
 }
-// issue pieces nq + 4 i (i = 0 .. ) of K tile kt into the stage at `stage_base`
+// issue pieces nq + 4 i (i = 0 .. ) of K tile kt into the stage at `stage_base`.
+// Addressing: everything that changes from piece to piece and from K tile to K tile is wave-uniform - it goes into the SCALAR base of
+// the request (s_add / s_addc), the per-lane part (row inside the piece, swizzled chunk) is one 32-bit VGPR offset that is fixed for
+// the tile (global_load_lds_dwordx4 v_off, s[base:base+1]).  Only the last four A pieces of a tile can hold rows past the clip
+// (a tile has fewer than 32 padding rows: shape_ok) and keep the per-lane clamp.  Why it matters: a vector instruction of ANY wave
+// cannot issue while another wave of the SIMD streams MFMAs (tools/micro/issue_overlap.hip: 256 VALU adds beside an f32 MFMA stream
+// take as long as the stream; only SALU instructions pass), so the 5 - 6 address instructions per piece that the compiler used to spend
+// were not hidden by the Y waves' MFMAs - they were time in which the X waves' own MFMAs had not started.
+template <int AUX>
+TAMF_DEV void glds16_sv(const char* sbase /* uniform */, unsigned voff, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((tamf_gbl_void*)(sbase + (size_t)voff), (tamf_lds_void*)lds_wave_base, 16, 0, AUX);
+}
 template <class Op, class C>
 TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, int prow, int kt, char* stage_base) {
   constexpr int QS = 4;
   constexpr int NI_ = (C::NPIECE + QS - 1) / QS;
-  const char* Ab = (const char*)ga.A;
-  const char* Wb = (const char*)ga.W;
   const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
+  const char* Ak = (const char*)ga.A + (size_t)kt * GEMM_BKB;
+  const char* Wk = (const char*)ga.W + (size_t)kt * GEMM_BKB;
 #pragma unroll
   for (int i = 0; i < NI_; ++i) {
     const int q = nq + QS * i;
     if ((i + 1) * QS <= C::NPIECE || q < C::NPIECE) {
-      const char* src;
-      if (q < C::A_PIECES) {
+      if (QS * i + QS - 1 < C::A_PIECES - 4) {  // (compile time: pieces whose rows are inside every clip these tiles are used for)
+        glds16_sv<0>(Ak + (size_t)((unsigned)(QS * 8 * i) * ldaB), s.a0, stage_base + q * 1024);
+      } else if (q < C::A_PIECES) {
         const unsigned o = (q * 8 + prow < s.rows) ? s.a0 + (unsigned)(QS * 8 * i) * ldaB : s.a_last;
-        src = Ab + o;
+        glds16_sv<0>(Ak, o, stage_base + q * 1024);
       } else {
-        src = Wb + (s.w0 + (unsigned)clip_wperm<C::CHUNK>(32 * (i + s.hq)) * ldwB);
+        glds16_sv<0>(Wk + (size_t)((unsigned)clip_wperm<C::CHUNK>(32 * (i + s.hq)) * ldwB), s.w0, stage_base + q * 1024);
       }
-      glds16<0>(src + (long)kt * GEMM_BKB, stage_base + q * 1024);
     }
   }
 }
+
+// Wave priorities (f32).  While a wave streams MFMAs no other wave of its SIMD issues a vector instruction, whatever the priorities
+// (tools/micro/issue_overlap.hip) - but priorities decide who goes first when both are ready.  The Y waves multiply at static priority 2;
+// in f32 the X waves take priority 3 for everything that is NOT their MFMA stream (fragment reads, requests, epilogue) and 0 for the
+// MFMAs: their requests are out - and their epilogue stores on the way - before the long fp32 MFMA phases of the pair begin
+// (6.50 -> 6.31 ms per step at B = 64; the 16-bit modes lose 0.2 - 0.8 % with it and keep priority 0).  -DTAMF_CLIP_XPRIO=0: off (A/B)
+#ifndef TAMF_CLIP_XPRIO
+#define TAMF_CLIP_XPRIO 1
+#endif
+#if TAMF_CLIP_XPRIO
+#define TAMF_CLIP_XPRIO_HI if constexpr (Op::PREC == 0) __builtin_amdgcn_s_setprio(3);
+#define TAMF_CLIP_XPRIO_LO if constexpr (Op::PREC == 0) __builtin_amdgcn_s_setprio(0);
+#else
+#define TAMF_CLIP_XPRIO_HI
+#define TAMF_CLIP_XPRIO_LO
+#endif
 
 // X waves, one K tile: the fragments of the first row tiles are requested, then ALL pieces of the next K tile go out into
 // `nxt`, then the MFMAs run with the A fragments streamed two row tiles ahead.  `cur` and `nxt` are the two LDS stages and
@@ -196,6 +223,7 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
   constexpr int BKB = GEMM_BKB;
   constexpr int mh_dbg = 0;
   (void)dbg_on; (void)it_dbg; (void)lane_dbg; (void)mh_dbg;
+  TAMF_CLIP_XPRIO_HI
   int4 wf[NI][2];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -209,6 +237,7 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
   if (load_next) clip_issue<Op, C>(ga, src4, nq, prow, kt_next, nxt);
+  TAMF_CLIP_XPRIO_LO
   TAMF_CLIP_TS(1)
 #pragma unroll
   for (int mi = 0; mi < C::MSUBX; ++mi) {
@@ -528,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       sc = sc + 1 == NS ? 0 : sc + 1;
       sn = sn + 1 == NS ? 0 : sn + 1;
       if (++kt == KT) {  // the tile is complete: its rows go out while Y multiplies its last K tile
+        TAMF_CLIP_XPRIO_HI
         const int b = t / ntn, n0 = (t % ntn) * C::BN;
         // column constants, then the next interval's requests (the epilogue must not delay them; and vmcnt retires in order: the
         // constants are waited for with the requests still in flight), then the rows

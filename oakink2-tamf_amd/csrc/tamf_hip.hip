@@ -382,6 +382,7 @@ struct ClipLaunch {
   }
   static hipError_t launch(const Op*, const typename Op::elem_t* A, int lda, const typename Op::elem_t* W, int ldw, int n_clips,
                            int Sp, int N, int K, const Epi& epi, hipStream_t st) {
+    if (!shape_ok(Sp, N, K)) return hipErrorInvalidValue;  // (the kernel relies on it: fewer than 32 padding rows per tile, clip_issue)
     hipError_t e = prepare();
     if (e != hipSuccess) return e;
     static_assert(PARTS == 1 || PARTS == 2, "whole clips or their two row parts");
