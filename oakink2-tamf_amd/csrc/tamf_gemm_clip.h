@@ -174,15 +174,16 @@ TAMF_DEV void glds16_sv(const char* sbase /* uniform */, unsigned voff, char* ld
   __builtin_amdgcn_global_load_lds((tamf_gbl_void*)(sbase + (size_t)voff), (tamf_lds_void*)lds_wave_base, 16, 0, AUX);
 }
 template <class Op, class C>
-TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, int prow, int kt, char* stage_base) {
+TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, int prow, int kt, char* stage_base, int i0 = 0, int i1 = 1 << 20) {
   constexpr int QS = 4;
-  constexpr int NI_ = (C::NPIECE + QS - 1) / QS;
+  constexpr int NI_ = (C::NPIECE + QS - 1) / QS;  // requests of a loader wave per K tile; [i0, i1): the ones to issue now (constants after unrolling)
   const unsigned ldaB = (unsigned)(ga.lda * Op::EB), ldwB = (unsigned)(ga.ldw * Op::EB);
   const char* Ak = (const char*)ga.A + (size_t)kt * GEMM_BKB;
   const char* Wk = (const char*)ga.W + (size_t)kt * GEMM_BKB;
 #pragma unroll
   for (int i = 0; i < NI_; ++i) {
     const int q = nq + QS * i;
+    if (i < i0 || i >= i1) continue;
     if ((i + 1) * QS <= C::NPIECE || q < C::NPIECE) {
       if (QS * i + QS - 1 < C::A_PIECES - 4) {  // (compile time: pieces whose rows are inside every clip these tiles are used for)
         glds16_sv<0>(Ak + (size_t)((unsigned)(QS * 8 * i) * ldaB), s.a0, stage_base + q * 1024);
@@ -203,6 +204,9 @@ TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, i
 // (6.50 -> 6.31 ms per step at B = 64; the 16-bit modes lose 0.2 - 0.8 % with it and keep priority 0).  -DTAMF_CLIP_XPRIO=0: off (A/B)
 #ifndef TAMF_CLIP_XPRIO
 #define TAMF_CLIP_XPRIO 1
+#endif
+#ifndef TAMF_CLIP_SPREAD  // f32: LDS-DMA requests between the X waves' own MFMAs (clip_ktile_x; 0 = one batch ahead of them, A/B)
+#define TAMF_CLIP_SPREAD 2  // (requests behind every 8 MFMAs)
 #endif
 #if TAMF_CLIP_XPRIO
 #define TAMF_CLIP_XPRIO_HI if constexpr (Op::PREC == 0) __builtin_amdgcn_s_setprio(3);
@@ -236,7 +240,15 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
   }
-  if (load_next) clip_issue<Op, C>(ga, src4, nq, prow, kt_next, nxt);
+  // f32: the requests go out BETWEEN this wave's own MFMAs, behind its first row tiles.  Beside the Y wave's fp32 MFMA stream no
+  // request issues at all (tools/micro/issue_overlap.hip), so as one batch they ran after it - ~900 cycles per interval in which the
+  // address unit took its 16 cycles per piece and no SIMD of the CU multiplied; inside the wave's own stream a request costs an issue
+  // slot and the address unit works in the shadow of the 32-cycle MFMAs.  (Early row tiles: with two stages the data is due at the
+  // next barrier.)  The 16-bit modes keep the batch: their Y phase is as long as the address unit needs, and it passes requests.
+  constexpr bool SPREAD = TAMF_CLIP_SPREAD && Op::PREC == 0;
+  constexpr int NREQ = (C::NPIECE + 3) / 4, GROUPS = C::MSUBX * NI;  // a group = the 8 MFMAs of one (row tile, column tile) product
+  constexpr int PER = (NREQ + GROUPS - 1) / GROUPS > TAMF_CLIP_SPREAD ? (NREQ + GROUPS - 1) / GROUPS : TAMF_CLIP_SPREAD;
+  if (load_next && !SPREAD) clip_issue<Op, C>(ga, src4, nq, prow, kt_next, nxt);
   TAMF_CLIP_XPRIO_LO
   TAMF_CLIP_TS(1)
 #pragma unroll
@@ -250,6 +262,13 @@ TAMF_DEV void clip_ktile_x(const char* __restrict__ cur, char* __restrict__ nxt,
       for (int ni = 0; ni < NI; ++ni) {
         if constexpr (TR) Op::mma_t(acc[mi][ni], af[mi], wf[ni]);  // D rows = m (4g + reg), cols = n (lr)
         else Op::mma(acc[mi][ni], wf[ni], af[mi]);                 // D rows = n (4g + reg), cols = m (lr)
+        if constexpr (SPREAD) {
+          if ((mi * NI + ni) * PER < NREQ) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (load_next) clip_issue<Op, C>(ga, src4, nq, prow, kt_next, nxt, (mi * NI + ni) * PER, (mi * NI + ni + 1) * PER);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
   }
