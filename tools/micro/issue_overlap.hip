@@ -34,8 +34,6 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, const float* g
         if (MF == 0) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
         else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[i], 0, 0, 0);
         if (PACE == 101) { asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3" : "+v"(fv[0]), "+v"(fv[1]), "+v"(fv[2]), "+v"(fv[3])); }
-        else if (PACE == 102) { f4 q = *(volatile f4*)&lds[((lane + i * 64) & 1023) * 4]; fr += q; }
-        else if (PACE == 103) { asm volatile("s_add_i32 %0, %0, 3\n\ts_add_i32 %0, %0, 3\n\ts_add_i32 %0, %0, 3\n\ts_add_i32 %0, %0, 3" : "+s"(fs)); }
         else if (PACE == 104) { asm volatile("v_add_f32 %0, %0, %0" : "+v"(fv[0])); }
         else if (PACE >= 24) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
         else if (PACE >= 16) asm volatile("s_nop 7\n\ts_nop 7");
@@ -87,9 +85,9 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, const float* g
 template <int KIND, int MF, int PACE = 0>
 static void run(const char* name, unsigned long long* out, const float* g, hipStream_t st) {
   static unsigned long long h[3072];
-  const int cfg[4][3] = {{0, 0, 0}, {1, 0, 2}, {1, 3, 2}, {1, 0, 0}};
-  const char* cn[4] = {"probe alone", "beside MFMAs, X prio 0 / Y 2", "beside MFMAs, X prio 3 / Y 2", "beside MFMAs, both prio 0"};
-  for (int c = 0; c < 4; ++c) {
+  const int cfg[3][3] = {{0, 0, 0}, {1, 0, 2}, {1, 3, 2}};
+  const char* cn[3] = {"probe alone", "beside MFMAs, X prio 0 / Y 2", "beside MFMAs, X prio 3 / Y 2"};
+  for (int c = 0; c < 3; ++c) {
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL((k<KIND, MF, PACE>), dim3(256), dim3(512), 0, st, out, g, cfg[c][0], cfg[c][1], cfg[c][2]);
       (void)hipStreamSynchronize(st);
@@ -105,16 +103,24 @@ int main() {
   hipStream_t st; (void)hipStreamCreate(&st);
   unsigned long long* out; (void)hipMalloc(&out, 16384 * 8); (void)hipMemset(out, 0, 16384 * 8);
   float* g; (void)hipMalloc(&g, 256 * 64 * 256 * 4); (void)hipMemset(g, 0, 256 * 64 * 256 * 4);
+  printf("== a probe wave beside another wave's back-to-back MFMA stream (same SIMD)\n");
+  run<0, 0>("256 VALU adds | f32 16x16x4 MFMAs", out, g, st);
+  run<1, 0>("256 SALU adds | f32 16x16x4 MFMAs", out, g, st);
+  run<2, 0>("64 ds_read_b128 | f32 16x16x4 MFMAs", out, g, st);
+  run<3, 0>("64 global_load_dwordx4 | f32 16x16x4 MFMAs", out, g, st);
+  run<0, 1>("256 VALU adds | f16 16x16x32 MFMAs", out, g, st);
+  run<2, 1>("64 ds_read_b128 | f16 16x16x32 MFMAs", out, g, st);
+  run<3, 1>("64 global_load_dwordx4 | f16 16x16x32 MFMAs", out, g, st);
+  printf("== the MFMA stream paced with s_nop behind every MFMA (the probe gets through, the stream pays the full nop)\n");
+  run<0, 0, 4>("256 VALU adds | f32 MFMAs + s_nop 3", out, g, st);
+  run<0, 0, 8>("256 VALU adds | f32 MFMAs + s_nop 7", out, g, st);
+  run<2, 0, 8>("64 ds_read_b128 | f32 MFMAs + s_nop 7", out, g, st);
+  run<0, 1, 4>("256 VALU adds | f16 MFMAs + s_nop 3", out, g, st);
+  printf("== other instructions inside the MFMA wave's own stream (column Y: what they cost the stream)\n");
   run<1, 0, 0>("f32 MFMAs, nothing between", out, g, st);
-  run<1, 0, 101>("f32 MFMAs, 4 independent v_add behind each (same wave)", out, g, st);
   run<1, 0, 104>("f32 MFMAs, 1 v_add behind each (same wave)", out, g, st);
-  run<1, 0, 102>("f32 MFMAs, 1 ds_read_b128 behind each (same wave)", out, g, st);
-  run<1, 0, 103>("f32 MFMAs, 4 s_add behind each (same wave)", out, g, st);
-  run<1, 0, 4>("f32 MFMAs, s_nop 3 behind each", out, g, st);
+  run<1, 0, 101>("f32 MFMAs, 4 independent v_add behind each", out, g, st);
   run<1, 1, 0>("f16 MFMAs, nothing between", out, g, st);
   run<1, 1, 104>("f16 MFMAs, 1 v_add behind each (same wave)", out, g, st);
-  run<1, 1, 102>("f16 MFMAs, 1 ds_read_b128 behind each (same wave)", out, g, st);
-  run<0, 0, 101>("X: 256 VALU adds | Y: f32 MFMAs + 4 v_add behind each", out, g, st);
-  run<2, 0, 102>("X: 64 ds_read | Y: f32 MFMAs + 1 ds_read behind each", out, g, st);
   return 0;
 }
