@@ -205,6 +205,9 @@ TAMF_DEV void clip_issue(const ClipGemmArgs<Op>& ga, const ClipSrc& s, int nq, i
 #ifndef TAMF_CLIP_XPRIO
 #define TAMF_CLIP_XPRIO 1
 #endif
+#ifndef TAMF_CLIP_YFUSE  // Y waves read the next K tile's fragments inside their MFMA stream (clip_mma_read_y): bit 0 = f32, bit 1 = the 16-bit modes (A/B)
+#define TAMF_CLIP_YFUSE 1  // (f32 6.30 -> 6.235 ms per step; the 16-bit modes 0.2 - 0.8 % slower with it: profiles/r04/yfuse_c36.txt)
+#endif
 #ifndef TAMF_CLIP_SPREAD  // f32: LDS-DMA requests between the X waves' own MFMAs (clip_ktile_x; 0 = one batch ahead of them, A/B)
 #define TAMF_CLIP_SPREAD 2  // (requests behind every 8 MFMAs)
 #endif
@@ -286,6 +289,36 @@ TAMF_DEV void clip_read_y(const char* cur, int a_frag, int w_frag, int c0, int c
   for (int mi = 0; mi < C::MSUBY; ++mi) {
     af[mi][0] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c0);
     af[mi][1] = *(const int4*)(cur + a_frag + mi * 16 * BKB + c1);
+  }
+}
+// Y waves, fused form: the MFMAs of K tile j - 1 row tile by row tile, and behind the MFMAs of a row tile the A fragments of K tile j
+// for that row tile, read into the registers the MFMAs have just consumed (no second fragment set); the W fragments follow behind
+// the last row tile.  An LDS read inside the wave's own MFMA stream costs a few cycles (MI355X_MICROARCH.md, LDS: "issued between
+// MFMAs"), while behind the stream the reads of the four Y waves compete with the X waves' reads for the LDS array and for issue slots.
+template <class Op, class C, int NI, bool TR>
+TAMF_DEV void clip_mma_read_y(const char* nxt, bool more, int a_frag, int w_frag, int c0, int c1, int4 (&wf)[NI][2],
+                              int4 (&af)[C::MSUBY][2], f32x4 (&acc)[C::MSUB0][NI]) {
+  constexpr int BKB = GEMM_BKB;
+#pragma unroll
+  for (int mi = 0; mi < C::MSUBY; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if constexpr (TR) Op::mma_t(acc[mi][ni], af[mi], wf[ni]);
+      else Op::mma(acc[mi][ni], wf[ni], af[mi]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      af[mi][0] = *(const int4*)(nxt + a_frag + mi * 16 * BKB + c0);
+      af[mi][1] = *(const int4*)(nxt + a_frag + mi * 16 * BKB + c1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (more) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      wf[ni][0] = *(const int4*)(nxt + w_frag + ni * 16 * BKB + c0);
+      wf[ni][1] = *(const int4*)(nxt + w_frag + ni * 16 * BKB + c1);
+    }
   }
 }
 template <class Op, class C, int NI, bool TR>
@@ -636,7 +669,10 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
       const int it_dbg = j, lane_dbg = lane, mh_dbg = 1;
 #endif
       TAMF_CLIP_TS(0)
-      if (!(TAMF_ABL(ga.abl) & 2)) clip_mma_y<Op, C, NI, TR>(ywf, yaf, acc);  // K tile j - 1
+      // (at 256 columns the fused form needs > 256 registers with 7 row tiles in Y: f32 gives its Y waves 6 there, tamf_hip.hip ClipXsub)
+      constexpr bool YFUSE = (NI == 2 || C::MSUBY <= 6) && (TAMF_CLIP_YFUSE & (Op::PREC == 0 ? 1 : 2)) != 0;
+      if constexpr (YFUSE) clip_mma_read_y<Op, C, NI, TR>(smem + sc * C::STAGE, j < J, a_frag, w_frag, c0, c1, ywf, yaf, acc);  // K tile j - 1, fragments of K tile j
+      else if (!(TAMF_ABL(ga.abl) & 2)) clip_mma_y<Op, C, NI, TR>(ywf, yaf, acc);  // K tile j - 1
 #ifdef TAMF_TIMELINE
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[C::MSUBY - 1][NI - 1][3]));  // the stamp waits for the MFMA results
 #endif
@@ -668,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         t = clip_tile_of(ga.n_tiles, ++round);
       }
       if (j == J) break;
-      clip_read_y<C, NI>(smem + sc * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
+      if constexpr (!YFUSE) clip_read_y<C, NI>(smem + sc * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);
 #ifdef TAMF_TIMELINE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif

@@ -346,15 +346,20 @@ template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true
 #ifndef TAMF_CLIP_XSUB_PARTS  // X : Y row tiles of the 7- / 6-row-tile parts (A/B knob; FFN2 at B = 32: 2 : 5 46 us, 3 : 4 60 us, 4 : 3 slower still)
 #define TAMF_CLIP_XSUB_PARTS 2
 #endif
-template <int NI, int NSUB, int PARTS>
+#ifndef TAMF_CLIP_YSUB_F32_N4  // f32 at 256 columns: row tiles of the Y waves (6: they read the next K tile's fragments inside their MFMA stream,
+#define TAMF_CLIP_YSUB_F32_N4 6  // clip_mma_read_y, which does not fit the registers with 7; in f32 nothing of X overlaps Y's MFMAs, so the split is free)
+#endif
+template <int NI, int NSUB, int PARTS, int PREC>
 struct ClipXsub {
-  static constexpr int value = PARTS > 1 ? TAMF_CLIP_XSUB_PARTS : NI >= 4 ? TAMF_CLIP_XSUB_N4 - (13 - NSUB + 1) / 2 : TAMF_CLIP_XSUB_N2;
+  static constexpr int value = PARTS > 1 ? TAMF_CLIP_XSUB_PARTS
+                               : NI >= 4 ? (PREC == 0 ? NSUB - TAMF_CLIP_YSUB_F32_N4 : TAMF_CLIP_XSUB_N4 - (13 - NSUB + 1) / 2)
+                                         : TAMF_CLIP_XSUB_N2;
 };
 // NSUB: row tiles of a TILE.  PARTS = 1: the tile is a whole clip; PARTS = 2: every clip is cut into its first NSUB row tiles and
 // the rest (NSUB or NSUB - 1 of them), each a tile of its own - for launches whose whole-clip tiles would fill at most half of the CUs
 template <class Op, int NI, class Epi, int NSUB = 13, int PARTS = 1>
 struct ClipLaunch {
-  static constexpr int XSUB = ClipXsub<NI, NSUB, PARTS>::value;
+  static constexpr int XSUB = ClipXsub<NI, NSUB, PARTS, Op::PREC>::value;
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   static constexpr int CLIP_ROWS_MAX = PARTS * C::MT;  // padded rows of the longest clip these tiles hold
   static hipError_t prepare() {
