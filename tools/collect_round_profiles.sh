@@ -60,6 +60,8 @@ PY
   rm -rf $out/pmc_${dt}_FETCH_SIZE $out/pmc_${dt}_WRITE_SIZE
   python3 bench.py --no-power --steps 1 --warmup 1 --no-cpu-baseline --also "" --fp32-loops 0 --dtype $dt --profile-out $out/step_profile_$dt.json > $out/step_$dt.log 2>&1
 done
+# the traffic files of THIS tree go where bench.py looks for them (roofline.traffic / traffic_stale) before the bench lines are taken
+if [ -d profiles/${TAMF_ROUND:-r04} ]; then cp $out/hbm_traffic_*.json profiles/${TAMF_ROUND:-r04}/; fi
 timeout 900 python3 bench.py > $out/bench_default.log 2>&1
 tail -n 1 $out/bench_default.log | cut -c1-600
 # the clip length the reference's dataset emits (T = 160) and the two 8-GPU presets' per-GPU shards, one line each
