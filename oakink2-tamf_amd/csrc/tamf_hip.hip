@@ -563,6 +563,14 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
 
 static inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+// Keys per V^T row (the row stride of Vt_op): the sequence rounded up to whole 32-key blocks - and at least the rows of the clip tile
+// that writes V^T in f32 (EpiVt stores every row tile of its 208- / 176-row tile, zeros past the clip: T = 174 is S = 179, 192 keys in
+// blocks, but 13 row tiles = 208 stored positions - they ran into the next feature's row and, for the last one, past the buffer)
+static inline int vt_row_keys(int S, int Sp) {
+  const int tile = (Sp > 176 && Sp <= 208) ? 208 : (Sp > 144 && Sp <= 176) ? 176 : 0;
+  return round_up(S > tile ? S : tile, 32);
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -637,7 +645,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, "hipStreamCreate failed"));
 
-  const int Smax = max_frames + ctx->P, Spmax = round_up(Smax, 8), Skpmax = round_up(Smax, 32);
+  const int Smax = max_frames + ctx->P, Spmax = round_up(Smax, 8), Skpmax = round_up(Smax > 208 ? Smax : 208, 32);  // (>= vt_row_keys of every shape)
   const long BT = (long)max_batch * max_frames;
   const long Mmax = (long)max_batch * Spmax;
   ctx->Mmax = Mmax;
@@ -943,7 +951,7 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
   ctx->T = T;
   ctx->S = T + P;
   ctx->Sp = round_up(ctx->S, 8);
-  ctx->Skp = round_up(ctx->S, 32);
+  ctx->Skp = vt_row_keys(ctx->S, ctx->Sp);
   ctx->M = B * ctx->Sp;
   ctx->cond_set = false;
   int j = 0;

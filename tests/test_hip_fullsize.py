@@ -239,6 +239,65 @@ def test_forward_clip_tiles_with_padded_rows(prec):
     ctx.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+@pytest.mark.parametrize("B,T", [(64, 174), (64, 147), (32, 188)])
+def test_forward_clip_tiles_at_their_largest_padding(prec, B, T):
+    """The clip tiles stage the rows of a clip with the per-lane row clamp only on their last four 8-row pieces (csrc/tamf_gemm_clip.h,
+    clip_issue): the shapes with the MOST padding rows each tile family accepts - T = 174: Sp = 184 of a 208-row tile (24 padding rows);
+    T = 147: Sp = 152 of a 176-row tile (24); B = 32, T = 188: Sp = 200 as row parts 112 + 88 (24 in the second part).  Against the
+    oracle on all clips."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    cond = O.det_cond(B, T, tag="maxpad/c", arch=arch)
+    g = torch.Generator().manual_seed(1000 + T)
+    x = torch.randn(B, 99, 1, T, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd, arch, x, t, cond)
+    ctx = _make_ctx(arch, sd, B, T, prec)
+    _set_cond(ctx, cond)
+    out = ctx.denoise(x, t).cpu()
+    err = float((out - ref).abs().max())
+    print(f"max-padding forward[{prec}] B={B} T={T}: max|err| = {err:.3e}")
+    assert torch.isfinite(out).all() and err < FWD_TOL[prec], (prec, B, T, err)
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+@pytest.mark.parametrize("B", [64, 32])
+def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B):
+    """Every clip length from T = 139 to 204 (Sp = 144 .. 216: below, inside and above the 176- / 208-row clip tiles and their row
+    parts): the default kernels against the 128 x 128 / LayerNorm-fused tiles (selection 1: no clip tiles at all) - the same bits -
+    and finite.  (T = 172 .. 187 and 140 .. 155 used to run the f32 V^T clip tile past the V^T rows: vt_row_keys, csrc/tamf_hip.hip.)"""
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import lib
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    bad = []
+    try:
+        for T in list(range(139, 205, 4)) + [147, 155, 156, 171, 172, 179, 187, 188, 203, 204]:
+            cond = O.det_cond(B, T, tag="sweep/c", arch=arch)
+            g = torch.Generator().manual_seed(T)
+            x = torch.randn(B, 99, 1, T, generator=g)
+            t = torch.randint(0, 1000, (B,), generator=g)
+            ctx = _make_ctx(arch, sd, B, T, prec)
+            _set_cond(ctx, cond)
+            lib().tamf_set_gemm_tuning(-1)
+            a = ctx.denoise(x, t).cpu()
+            lib().tamf_set_gemm_tuning((1 << 20) | 0xFFFFF)
+            b = ctx.denoise(x, t).cpu()
+            lib().tamf_set_gemm_tuning(-1)
+            ctx.close()
+            if not (torch.isfinite(a).all() and torch.equal(a, b)):
+                bad.append((T, float((a - b).abs().max())))
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+    assert not bad, (prec, B, bad)
+
+
 # selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
 # one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
 SELECTIONS = {
