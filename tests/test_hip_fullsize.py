@@ -298,6 +298,43 @@ def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B):
     assert not bad, (prec, B, bad)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+@pytest.mark.parametrize("T", [196, 160])
+def test_kernel_choice_over_batch_sizes(prec, T):
+    """The launch rules switch kernels with the batch size (clip tiles from 74 % fill, row-part tiles up to half the CUs, query splits of the
+    attention, 64-row tiles for short-K GEMMs, two-kernel LayerNorm forms for under-filled tiles): at 24 batch sizes from 1 to 128 the default
+    kernels against selection 1 (no clip tiles anywhere) - the same bits - and clip 0 of every batch against clip 0 alone."""
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import lib
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    BMAX = 128
+    cond = O.det_cond(BMAX, T, tag="bsweep/c", arch=arch)
+    g = torch.Generator().manual_seed(7 + T)
+    x = torch.randn(BMAX, 99, 1, T, generator=g)
+    t = torch.randint(0, 1000, (BMAX,), generator=g)
+    bad = []
+    alone = None
+    try:
+        for B in [1, 2, 3, 5, 8, 13, 16, 21, 24, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 72, 96, 127, 128]:
+            ctx = _make_ctx(arch, sd, B, T, prec)
+            _set_cond(ctx, _sub(cond, slice(0, B)))
+            lib().tamf_set_gemm_tuning(-1)
+            a = ctx.denoise(x[:B], t[:B]).cpu()
+            lib().tamf_set_gemm_tuning((1 << 20) | 0xFFFFF)
+            b = ctx.denoise(x[:B], t[:B]).cpu()
+            lib().tamf_set_gemm_tuning(-1)
+            ctx.close()
+            if alone is None:
+                alone = a[0].clone()
+            if not (torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[0], alone)):
+                bad.append((B, float((a - b).abs().max()), float((a[0] - alone).abs().max())))
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+    assert not bad, (prec, T, bad)
+
+
 # selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
 # one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
 SELECTIONS = {
