@@ -335,6 +335,55 @@ def test_kernel_choice_over_batch_sizes(prec, T):
     assert not bad, (prec, T, bad)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+def test_refine_and_loop_over_clip_lengths(prec):
+    """The R trunk (3 prefix tokens: S = T + 3) and the hipGraph sampling loop of G (20 steps, device Philox) over clip lengths around
+    the clip tiles' limits, B = 64: default kernels against selection 1 (no clip tiles) - the same bits, finite."""
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import lib
+
+    bad = []
+    try:
+        arch = O.ARCH_REFINE
+        sd = O.det_state_dict(arch, tag="fullr/w")
+        for T in [141, 150, 158, 160, 173, 174, 176, 181, 189, 190, 196, 205]:
+            cond = O.det_cond(64, T, tag="rsweep/c", arch=arch)
+            g = torch.Generator().manual_seed(T)
+            x_in = torch.randn(64, T, 99, generator=g)
+            h2o = torch.rand(64, T, 778, generator=g) * 0.2
+            ctx = _make_ctx(arch, sd, 64, T, prec)
+            _set_cond(ctx, cond)
+            lib().tamf_set_gemm_tuning(-1)
+            a = ctx.refine(x_in, h2o).cpu()
+            lib().tamf_set_gemm_tuning((1 << 20) | 0xFFFFF)
+            b = ctx.refine(x_in, h2o).cpu()
+            lib().tamf_set_gemm_tuning(-1)
+            ctx.close()
+            if not (torch.isfinite(a).all() and torch.equal(a, b)):
+                bad.append(("refine", T, float((a - b).abs().max())))
+        arch = O.ARCH_MDM_L
+        sd = O.det_state_dict(arch, tag="full/w")
+        tab = O.make_tables(20, "cosine")
+        for T in [147, 160, 174, 187, 188, 196]:
+            cond = O.det_cond(64, T, tag="lsweep/c", arch=arch)
+            outs = []
+            for tune in (-1, (1 << 20) | 0xFFFFF):
+                lib().tamf_set_gemm_tuning(tune)
+                ctx = _make_ctx(arch, sd, 64, T, prec)
+                _set_cond(ctx, cond)
+                ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+                out = torch.empty(64, 99, 1, T, device="cuda")
+                ctx.sample_loop(seed=5, out=out)
+                outs.append(out.cpu())
+                ctx.close()
+            lib().tamf_set_gemm_tuning(-1)
+            if not (torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])):
+                bad.append(("loop", T, float((outs[0] - outs[1]).abs().max())))
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+    assert not bad, (prec, bad)
+
+
 # selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
 # one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
 SELECTIONS = {
