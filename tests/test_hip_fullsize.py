@@ -384,6 +384,38 @@ def test_refine_and_loop_over_clip_lengths(prec):
     assert not bad, (prec, bad)
 
 
+def test_modes_agree_on_random_shapes():
+    """48 random (B, T) shapes, B in [1, 130], T in [8, 204] - most of them shapes no other test visits: the four arithmetic modes run
+    different kernels for the same launch (f32: clip tiles for QKV and out-proj, its own LayerNorm forms; bf16: LayerNorm fused into
+    FFN2; the split modes: neither), so a slip in one mode's path shows as a disagreement far above the modes' rounding differences."""
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_MDM_L
+    sd = O.det_state_dict(arch, tag="full/w")
+    rng = np.random.RandomState(20261003)
+    shapes = [(int(rng.randint(1, 131)), int(rng.randint(8, 205))) for _ in range(48)]
+    tol = {"f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 6e-2}
+    bad = []
+    for B, T in shapes:
+        cond = O.det_cond(B, T, tag="rand/c", arch=arch)
+        g = torch.Generator().manual_seed(B * 1000 + T)
+        x = torch.randn(B, 99, 1, T, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        outs = {}
+        for prec in ["f32", "f16x3", "bf16x3", "bf16"]:
+            ctx = _make_ctx(arch, sd, B, T, prec)
+            _set_cond(ctx, cond)
+            outs[prec] = ctx.denoise(x, t).cpu()
+            ctx.close()
+        for prec, tl in tol.items():
+            d = float((outs[prec] - outs["f32"]).abs().max())
+            if not (torch.isfinite(outs[prec]).all() and d < tl):
+                bad.append((B, T, prec, d))
+        if not torch.isfinite(outs["f32"]).all():
+            bad.append((B, T, "f32", float("nan")))
+    assert not bad, bad
+
+
 # selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
 # one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
 SELECTIONS = {
