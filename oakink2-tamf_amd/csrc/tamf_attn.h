@@ -23,6 +23,7 @@ struct AttnArgs {
   int S, Sp, Skp, d, H;
   int abl;  // kernel-benchmark ablations of attn_res_kernel (-DTAMF_BENCH builds only, TAMF_ABL; tools/attn_bench.py): 1 = no LDS-DMA,
             // 2 = no MFMAs, 4 = no fragment reads, 8 = no exp2 / hi-lo split, 16 = no output store
+  int ksplit;  // attn_res_kernel: the clip's LAST query tile is computed by four waves, a quarter of the key blocks each (set by launch_attn)
 };
 
 template <class Op, int HD>
@@ -314,6 +315,22 @@ struct AttnRes {
     return need > rows ? need : rows;
   }
 
+  // key split of the last query tile (attn_res_kernel): bytes of the partial area (3 foreign partials per 128-byte row group + m / l),
+  // and how much the allocation grows for nwq tile-owning waves - or -1 when it does not fit
+  static constexpr int TPC_ = EB == 4 ? 2 : 4, NCH_ = (NT16 + TPC_ - 1) / TPC_, TPCE_ = NT16 < TPC_ ? NT16 : TPC_;
+  static constexpr int KSPLIT_BYTES = NCH_ * 3 * TPCE_ * 1024 + 512;
+  static int ksplit_extra(int S, int Sp, int nwq) {
+    const int nkb = (S + 31) / 32, n1 = nv1(Sp, nkb), base = smem(S, Sp);
+    int extra;
+    if (n1 < nkb) {  // inside the first V^T area, behind the nwq output slots of 2 KiB; whatever sticks out is allocated on top
+      const int end = k_bytes(Sp) + nwq * 2048 + KSPLIT_BYTES;
+      extra = end > base ? end - base : 0;
+    } else {
+      extra = KSPLIT_BYTES;
+    }
+    return base + extra <= LDS_MAX ? extra : -1;
+  }
+
   // K rows [r0, r1) (multiples of K_RPP): piece q covers rows [q K_RPP, (q + 1) K_RPP)
   static TAMF_DEV void issue_k(char* Ks, const char* kbase, int r0, int r1, int d, int wave, int nw, int lane) {
     const int q0 = r0 / BLK::K_RPP, np = r1 / BLK::K_RPP;
@@ -362,7 +379,7 @@ struct AttnRes {
   template <int T0, int T1>
   static TAMF_DEV void scores(const char* __restrict__ Ks, char* __restrict__ K2, char* __restrict__ Vs, const char* kbase,
                               const char* vbase, int k2r0, int k2r1, int d, int n1, int Skp, int wave, int nw, int lane,
-                              const int4 (&qf)[KG][2], f32x4 (&st)[NKT], int abl) {
+                              const int4 (&qf)[KG][2], f32x4 (&st)[NKT], int abl, unsigned mask = ~0u) {
     const int lr = lane & 15, g = lane >> 4;
     if (T0 == 0 && !(abl & 1)) {
       if (k2r1 > k2r0) issue_k(K2 - (long)k2r0 * C::KROWB, kbase, k2r0, k2r1, d, wave, nw, lane);
@@ -373,15 +390,20 @@ struct AttnRes {
     int4 kf[LA + 1][2];
 #pragma unroll
     for (int i = 0; i <= LA; ++i) kf[i][0] = kf[i][1] = qf[0][0];  // (defined contents for the no-read ablation)
+    // `mask`: bit kb = this wave multiplies key block kb (wave-uniform; all ones but for the key-split waves of the last query tile);
+    // a skipped tile keeps the -1e30 the caller put there
+    auto on = [&](int i) { return ((mask >> (i / KG / 2)) & 1u) != 0; };
 #pragma unroll
     for (int i = F0; i < F0 + LA; ++i)
-      if (!(abl & 4)) kfrag(Ks, i, ko, kf[i % (LA + 1)]);
+      if (!(abl & 4) && on(i)) kfrag(Ks, i, ko, kf[i % (LA + 1)]);
 #pragma unroll
     for (int i = F0; i < NF; ++i) {
-      if (i + LA < NF && !(abl & 4)) kfrag(Ks, i + LA, ko, kf[(i + LA) % (LA + 1)]);
+      if (i + LA < NF && !(abl & 4) && on(i + LA)) kfrag(Ks, i + LA, ko, kf[(i + LA) % (LA + 1)]);
       __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks each read to its use: read, lgkmcnt(0), three MFMAs, ...)
-      if (i % KG == 0) st[i / KG] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!(abl & 2)) Op::mma(st[i / KG], kf[i % (LA + 1)], qf[i % KG]);
+      if (on(i)) {
+        if (i % KG == 0) st[i / KG] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(abl & 2)) Op::mma(st[i / KG], kf[i % (LA + 1)], qf[i % KG]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -394,13 +416,13 @@ struct AttnRes {
   // that the blocks [dkb0, dkb1) are requested into `dma_dst` (never overlapping Vs)
   static TAMF_DEV void pv(const char* __restrict__ Vs, char* __restrict__ dma_dst, const char* vbase, int kb0, int kb1, int dkb0,
                           int dkb1, int Skp, int wave, int nw, int lane, const uint32_t (&ph)[NKB][4], const uint32_t (&pl)[NKB][4],
-                          f32x4 (&o)[NT16], int abl) {
+                          f32x4 (&o)[NT16], int abl, unsigned mask = ~0u) {
     const int lr = lane & 15, g = lane >> 4;
     const int vo0 = lr * C::VSTR + BLK::vswz(g, lr) * 16, vo1 = lr * C::VSTR + BLK::vswz(4 + g, lr) * 16;
     if (dkb1 > dkb0 && !(abl & 1)) issue_v(dma_dst, vbase, dkb0, dkb1, Skp, wave, nw, lane);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb >= kb0 && kb < kb1) {  // (wave-uniform)
+      if (kb >= kb0 && kb < kb1 && ((mask >> kb) & 1u)) {  // (wave-uniform)
         const char* vb = Vs + (kb - kb0) * C::V_BYTES;
         const int4 p_h = make_int4((int)ph[kb][0], (int)ph[kb][1], (int)ph[kb][2], (int)ph[kb][3]);
         const int4 p_l = make_int4((int)pl[kb][0], (int)pl[kb][1], (int)pl[kb][2], (int)pl[kb][3]);
@@ -465,8 +487,32 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
   if (gridDim.x == 1 && !(TAMF_ABL(aa.abl) & 32)) bh = attn_xcd_remap(bh, gridDim.y);
 #endif
   const int b = bh / aa.H, h = bh % aa.H;
-  const int q0 = (blockIdx.x * nw + wave) * 16;
   const int S = aa.S, Sp = aa.Sp, d = aa.d;
+  // Key split of the clip's LAST query tile (aa.ksplit; launch_attn sets it when the clip has 4 n + 1 query tiles, e.g. 13 at T = 196).
+  // The waves of a SIMD run their MFMA streams one after the other (per-wave phase stamps, f32: the score pass of waves 0 / 4 / 8 / 12
+  // - SIMD 0 - ends after 9 900 / 17 300 / 24 800 / 32 100 ticks, the three waves of the other SIMDs after 24 600, and everybody waits at
+  // the barrier for wave 12), so 13 tiles on 4 SIMDs cost 4 tile times, not 3.25.  The workgroup gets three extra waves; in the
+  // workgroup that holds the last tile its owner and the extras - one per SIMD - take the key blocks kb = hq mod 4 each (scores, exact
+  // softmax over THOSE keys, P V) and merge through LDS: O = sum_i O_i 2^(m_i - m), l = sum_i l_i 2^(m_i - m), i = 0..3 in that order.
+  // The rule depends on the clip's length only - never on the batch size or on how the queries are split over workgroups - so a
+  // clip's result stays independent of the batch it is in.
+  const int nwq = aa.ksplit ? nw - 3 : nw;  // waves that own a query tile
+  const int nqt = (Sp + 15) / 16;
+  int tile = blockIdx.x * nwq + (wave < nwq ? wave : nwq);
+  int hq = -1;                               // >= 0: key-split wave hq of the last tile
+  unsigned kmask = ~0u;                      // key blocks this wave multiplies
+  bool idle = false;                         // an extra wave outside the last tile's workgroup / a wave without a tile: loads and barriers only
+  if (aa.ksplit) {
+    if (wave >= nwq) {
+      if ((int)blockIdx.x == (nqt - 1) / nwq) { hq = wave - nwq + 1; tile = nqt - 1; } else idle = true;
+    } else if (tile == nqt - 1) {
+      hq = 0;
+    }
+    if (hq >= 0) kmask = 0x11111111u << hq;
+  }
+  if (tile >= nqt) idle = true;
+  if (idle) { kmask = 0u; tile = nqt - 1; }
+  const int q0 = tile * 16;
   const long row_base = (long)b * Sp;
   const int nkb = (S + 31) / 32;
   const int kbytes = Sp * C::KROWB;
@@ -500,9 +546,13 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
 
   // ---- pass 1: scores of this wave's 16 queries against all keys; V^T blocks [0, n1) fly underneath
   f32x4 st[NKT];
-  R::template scores<0, TH>(Ks, Ks + (long)kh * C::KROWB, Vs, kbase, vbase, kh, Sp, d, n1, aa.Skp, wave, nw, lane, qf, st, abl);
+  if (kmask != ~0u) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
+  }
+  R::template scores<0, TH>(Ks, Ks + (long)kh * C::KROWB, Vs, kbase, vbase, kh, Sp, d, n1, aa.Skp, wave, nw, lane, qf, st, abl, kmask);
   __syncthreads();  // the second half of K (and the V^T blocks) have landed
-  R::template scores<TH, NKT>(Ks, Vs, Vs, kbase, vbase, 0, 0, d, 0, aa.Skp, wave, nw, lane, qf, st, abl);
+  R::template scores<TH, NKT>(Ks, Vs, Vs, kbase, vbase, 0, 0, d, 0, aa.Skp, wave, nw, lane, qf, st, abl, kmask);
 
   // ---- exact softmax over the keys (per query = per lane column; the 4 lane groups hold disjoint keys)
 #pragma unroll
@@ -550,20 +600,78 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
 
   __syncthreads();  // V^T blocks [0, n1) have landed; nobody reads K any more
   // ---- pass 2: O^T = V^T P^T; the blocks that did not fit beside K are fetched into K's space meanwhile
-  R::pv(Vs, Ks, vbase, 0, n1, n1, nkb, aa.Skp, wave, nw, lane, ph, pl, o, abl);
+  R::pv(Vs, Ks, vbase, 0, n1, n1, nkb, aa.Skp, wave, nw, lane, ph, pl, o, abl, kmask);
   if (n1 < nkb) {
     __syncthreads();
-    R::pv(Ks, Vs, vbase, n1, nkb, 0, 0, aa.Skp, wave, nw, lane, ph, pl, o, abl);
+    R::pv(Ks, Vs, vbase, n1, nkb, 0, 0, aa.Skp, wave, nw, lane, ph, pl, o, abl, kmask);
+  }
+  if (idle) {  // (stores nothing; the barrier is the one the key-split waves wait at before their merge)
+    if (aa.ksplit) __syncthreads();
+    return;
   }
 
   // ---- output: the wave's 16 x HD tile goes through a lane-private 2-KiB LDS slot per 128-byte row group, so that a store
   // instruction writes whole 128-byte lines (8 rows x 128 B per dwordx4 wave-instruction) instead of 8-byte pieces of 16 rows:
   // the row-per-lane form (16 global_store_dwordx2 per lane) cost 7.7 of the kernel's 32 us (tools/attn_bench.py, ablation 16).
   // The slot lies in the part of LDS nobody reads in the last phase: the first V^T area when the blocks were split, K otherwise.
-  const float inv = 1.0f / l;
-  if ((abl & 16) && inv != 12345.0f) return;
+  if ((abl & 16) && l != 12345.0f) return;
   constexpr int TPC = Op::EB == 4 ? 2 : 4;     // feature tiles per 128-byte row group (32 f32 or split elements / 64 bf16)
   constexpr int NCH = (NT16 + TPC - 1) / TPC, TPCE = NT16 < TPC ? NT16 : TPC;
+  if (hq >= 0) {
+    // partials of the key-split waves: [row group ch][foreign helper 0..2][tile of the group] x 1 KiB (lane-major f32x4), then m / l of
+    // the four.  The area: behind the output slots of the tile-owning waves inside the first V^T area when V^T was fetched in two parts
+    // (nobody reads that area in the last phase; the helpers store directly and need no slot), else behind everything; launch_attn
+    // sizes the allocation (AttnRes::ksplit_extra)
+    const int base_bytes = kbytes + n1 * C::V_BYTES > NKT * 16 * C::KROWB ? kbytes + n1 * C::V_BYTES : NKT * 16 * C::KROWB;  // (= AttnRes::smem)
+    char* part = n1 < nkb ? Vs + nwq * 2048 : smem + base_bytes;
+    float* ml = (float*)(part + NCH * 3 * TPCE * 1024);
+    if (g == 0) { ml[hq * 32 + lr] = m; ml[hq * 32 + 16 + lr] = l; }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      if (ch != hq) {
+        const int src = hq < ch ? hq : hq - 1;
+#pragma unroll
+        for (int tl = 0; tl < TPCE; ++tl) *(f32x4*)(part + ((ch * 3 + src) * TPCE + tl) * 1024 + lane * 16) = o[ch * TPC + tl];
+      }
+    __syncthreads();  // the partials are in LDS (every wave of the workgroup comes here once: the others at the end of their stores)
+    if (hq >= NCH || q0 + lr >= Sp) return;
+    float mi[4], li[4], mg = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mi[i] = ml[i * 32 + lr]; li[i] = ml[i * 32 + 16 + lr]; mg = fmaxf(mg, mi[i]); }
+    float w[4], lg = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = __builtin_amdgcn_exp2f(mi[i] - mg); lg += li[i] * w[i]; }
+    const float invg = 1.0f / lg;
+    char* grow = (char*)aa.out + ((row_base + q0 + lr) * d + h * HD) * EB + hq * 128;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {  // (static indices into o[]: a run-time index would put the accumulators into scratch)
+      if (ch != hq) continue;
+#pragma unroll
+      for (int tl = 0; tl < TPCE; ++tl) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // (fixed order: helper 0, 1, 2, 3)
+          const f32x4 mine = o[ch * TPC + tl];
+          const f32x4 theirs = *(const f32x4*)(part + ((ch * 3 + (i < ch ? i : (i > 0 ? i - 1 : 0))) * TPCE + tl) * 1024 + lane * 16);
+          const f32x4 oi = i == ch ? mine : theirs;
+          acc += oi * w[i];
+        }
+        const float v0 = acc[0] * invg, v1 = acc[1] * invg, v2 = acc[2] * invg, v3 = acc[3] * invg;
+        if constexpr (Op::PREC == 0) {
+          *(int4*)(grow + (4 * tl + g) * 16) = make_int4(as_i(v0), as_i(v1), as_i(v2), as_i(v3));
+        } else {
+          uint32_t h0, l0, h1, l1;
+          Op::split2(v0, v1, h0, l0);
+          Op::split2(v2, v3, h1, l1);
+          char* gp = grow + (2 * tl + (g >> 1)) * 16 + 8 * (g & 1);  // (the layout of the slot rows below: hi plane, lo plane 64 bytes further)
+          *(int2*)gp = make_int2((int)h0, (int)h1);
+          if constexpr (Op::SPLIT) *(int2*)(gp + 64) = make_int2((int)l0, (int)l1);
+        }
+      }
+    }
+    return;
+  }
+  const float inv = 1.0f / l;
   // slot rows are 128 bytes (a wave's slot = 2 KiB <= the 16 K rows of its own queries, so the slots always fit the area they borrow),
   // their 16-byte chunks XOR-swizzled by the row: the 8-byte column writes of the 16 lanes of a group are two-way conflicts at worst
   constexpr int RS = 128;
@@ -601,4 +709,5 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
         *(int4*)(gout + (long)row * d * EB + ch * 128 + spiece * 16) = w;
     }
   }
+  if (aa.ksplit) __syncthreads();  // (the barrier the key-split waves wait at before their merge)
 }

@@ -520,6 +520,9 @@ static hipError_t prepare_all() {
   return hipSuccess;
 }
 
+#ifndef TAMF_ATTN_KSPLIT  // (0: A/B builds without the key split of the last query tile)
+#define TAMF_ATTN_KSPLIT 1
+#endif
 template <class Op>
 static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t st) {
   const int nqt = (aa.Sp + 15) / 16;
@@ -538,8 +541,16 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
     if (!(g_sel & 512)) {
 #define TAMF_TRY_RES(HD_, NKB_)                                                                            \
   if (hd == HD_ && AttnRes<Op, HD_, NKB_>::fits(aa.S, aa.Sp)) {                                           \
-    const int lds = AttnRes<Op, HD_, NKB_>::smem(aa.S, aa.Sp);                                             \
-    hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nw * 64), lds, st, aa);                \
+    int lds = AttnRes<Op, HD_, NKB_>::smem(aa.S, aa.Sp);                                                   \
+    AttnArgs<Op> a2 = aa;                                                                                  \
+    int nwl = nw;                                                                                          \
+    /* a clip of 4 n + 1 query tiles (13 at T = 196): its last tile is key-split over four waves (tamf_attn.h) - decided by the */ \
+    /* clip's length alone, so that a clip's result does not depend on the batch size or the query split */                       \
+    if (TAMF_ATTN_KSPLIT && nqt % 4 == 1 && nqt >= 5 && nw + 3 <= 16) {                                    \
+      const int extra = AttnRes<Op, HD_, NKB_>::ksplit_extra(aa.S, aa.Sp, nw);                             \
+      if (extra >= 0) { a2.ksplit = 1; nwl = nw + 3; lds += extra; }                                       \
+    }                                                                                                      \
+    hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nwl * 64), lds, st, a2);               \
     return hipGetLastError();                                                                              \
   }
       TAMF_TRY_RES(64, 4)   // up to 128 keys
