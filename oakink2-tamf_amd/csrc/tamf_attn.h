@@ -23,7 +23,10 @@ struct AttnArgs {
   int S, Sp, Skp, d, H;
   int abl;  // kernel-benchmark ablations of attn_res_kernel (-DTAMF_BENCH builds only, TAMF_ABL; tools/attn_bench.py): 1 = no LDS-DMA,
             // 2 = no MFMAs, 4 = no fragment reads, 8 = no exp2 / hi-lo split, 16 = no output store
-  int ksplit;  // attn_res_kernel: the clip's LAST query tile is computed by four waves, a quarter of the key blocks each (set by launch_attn)
+  // attn_res_kernel, set by launch_attn: the clip's LAST query tile is computed by four waves, a quarter of the key blocks each.
+  // nwq = query tiles per workgroup (the other tiles; waves 0 .. nwq-1 own them), hw = the wave indices of the four key-split waves in
+  // the LAST workgroup of the pair (4 bits each), chosen on the SIMDs that carry the fewest tiles there
+  int ksplit, nwq, hw;
 };
 
 template <class Op, int HD>
@@ -491,26 +494,25 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
   // Key split of the clip's LAST query tile (aa.ksplit; launch_attn sets it when the clip has 4 n + 1 query tiles, e.g. 13 at T = 196).
   // The waves of a SIMD run their MFMA streams one after the other (per-wave phase stamps, f32: the score pass of waves 0 / 4 / 8 / 12
   // - SIMD 0 - ends after 9 900 / 17 300 / 24 800 / 32 100 ticks, the three waves of the other SIMDs after 24 600, and everybody waits at
-  // the barrier for wave 12), so 13 tiles on 4 SIMDs cost 4 tile times, not 3.25.  The workgroup gets three extra waves; in the
-  // workgroup that holds the last tile its owner and the extras - one per SIMD - take the key blocks kb = hq mod 4 each (scores, exact
-  // softmax over THOSE keys, P V) and merge through LDS: O = sum_i O_i 2^(m_i - m), l = sum_i l_i 2^(m_i - m), i = 0..3 in that order.
-  // The rule depends on the clip's length only - never on the batch size or on how the queries are split over workgroups - so a
-  // clip's result stays independent of the batch it is in.
-  const int nwq = aa.ksplit ? nw - 3 : nw;  // waves that own a query tile
+  // the barrier for wave 12), so 13 tiles on 4 SIMDs cost 4 tile times, not 3.25.  The other tiles are dealt to the workgroups of
+  // the pair as before; the last one belongs to four extra waves of the pair's LAST workgroup, placed (by launch_attn) on the SIMDs
+  // that carry the fewest tiles there: wave hq takes the key blocks kb = hq mod 4 (scores, exact softmax over THOSE keys, P V) and
+  // they merge through LDS: O = sum_i O_i 2^(m_i - m), l = sum_i l_i 2^(m_i - m), i = 0..3 in that order.  WHICH waves compute the
+  // quarters depends on the batch (the query split); WHAT is computed depends on the clip's length only, so a clip's result stays
+  // independent of the batch it is in.
+  const int nwq = aa.ksplit ? aa.nwq : nw;   // waves that own a query tile
   const int nqt = (Sp + 15) / 16;
-  int tile = blockIdx.x * nwq + (wave < nwq ? wave : nwq);
+  const int nqt_own = aa.ksplit ? nqt - 1 : nqt;  // tiles dealt to tile-owning waves
+  int tile = blockIdx.x * nwq + wave;
   int hq = -1;                               // >= 0: key-split wave hq of the last tile
   unsigned kmask = ~0u;                      // key blocks this wave multiplies
-  bool idle = false;                         // an extra wave outside the last tile's workgroup / a wave without a tile: loads and barriers only
-  if (aa.ksplit) {
-    if (wave >= nwq) {
-      if ((int)blockIdx.x == (nqt - 1) / nwq) { hq = wave - nwq + 1; tile = nqt - 1; } else idle = true;
-    } else if (tile == nqt - 1) {
-      hq = 0;
-    }
-    if (hq >= 0) kmask = 0x11111111u << hq;
+  bool idle = wave >= nwq || tile >= nqt_own;  // loads and barriers only
+  if (aa.ksplit && blockIdx.x == gridDim.x - 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (wave == ((aa.hw >> (4 * j)) & 15)) hq = j;
+    if (hq >= 0) { idle = false; tile = nqt - 1; kmask = 0x11111111u << hq; }
   }
-  if (tile >= nqt) idle = true;
   if (idle) { kmask = 0u; tile = nqt - 1; }
   const int q0 = tile * 16;
   const long row_base = (long)b * Sp;

@@ -544,11 +544,22 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
     int lds = AttnRes<Op, HD_, NKB_>::smem(aa.S, aa.Sp);                                                   \
     AttnArgs<Op> a2 = aa;                                                                                  \
     int nwl = nw;                                                                                          \
-    /* a clip of 4 n + 1 query tiles (13 at T = 196): its last tile is key-split over four waves (tamf_attn.h) - decided by the */ \
-    /* clip's length alone, so that a clip's result does not depend on the batch size or the query split */                       \
-    if (TAMF_ATTN_KSPLIT && nqt % 4 == 1 && nqt >= 5 && nw + 3 <= 16) {                                    \
-      const int extra = AttnRes<Op, HD_, NKB_>::ksplit_extra(aa.S, aa.Sp, nw);                             \
-      if (extra >= 0) { a2.ksplit = 1; nwl = nw + 3; lds += extra; }                                       \
+    /* f32, a clip of 4 n + 1 query tiles (13 at T = 196): its last tile is key-split over four waves (tamf_attn.h) - decided by */ \
+    /* the clip's length alone, so that a clip's result does not depend on the batch size or the query split.  f32 only: the    */ \
+    /* 16-bit modes' waves overlap on a SIMD, the split buys them nothing at B = 64 and costs 1 - 3 % at B <= 32                 */ \
+    if (TAMF_ATTN_KSPLIT && Op::PREC == 0 && nqt % 4 == 1 && nqt >= 5) {                                   \
+      const int nwq = (nqt - 1 + chunks - 1) / chunks, nlast = nqt - 1 - (chunks - 1) * nwq > 0 ? nqt - 1 - (chunks - 1) * nwq : 0; \
+      /* the four key-split waves go to the SIMDs with the fewest tiles in the last workgroup (wave w runs on SIMD w mod 4) */     \
+      const int r = nlast % 4, nlight = r ? 4 - r : 4;                                                     \
+      int hw = 0, top = nwq, used = 0;                                                                     \
+      for (int j = 0; j < 4; ++j) {                                                                        \
+        const int simd = (r ? r : 0) + j % nlight;                                                         \
+        int idx = nlast + ((simd - nlast % 4) + 4) % 4;                                                    \
+        while (used & (1 << idx)) idx += 4;                                                                \
+        used |= 1 << idx; hw |= idx << (4 * j); if (idx + 1 > top) top = idx + 1;                          \
+      }                                                                                                    \
+      const int extra = AttnRes<Op, HD_, NKB_>::ksplit_extra(aa.S, aa.Sp, nwq);                            \
+      if (extra >= 0 && top <= 16) { a2.ksplit = 1; a2.nwq = nwq; a2.hw = hw; nwl = top; lds += extra; }   \
     }                                                                                                      \
     hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nwl * 64), lds, st, a2);               \
     return hipGetLastError();                                                                              \
