@@ -11,6 +11,7 @@ Contract (one JSON line on rank 0's stdout):
 A "step" is ONE complete reverse loop (n_ddpm = 1000 DDPM steps, hipGraph-replayed) over one batch of synthetic
 clips.  Workload presets (--config): 2 = BASELINE.json configs[1] (arch_mdm_l, 64 clips per GPU, T = 196; the default),
 3 = configs[2] (32 clips per GPU: B = 256 over 8 GPUs), 5 = configs[4] (bf16, 64 clips per GPU: B = 512 over 8 GPUs).
+4 = configs[3] (arch_refine trunk, B = 64, T = 196: one forward per step, 1 GPU only).
 Clips are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is the RCCL
 all_gather of the sampled poses at the end of every loop, which is inside the timed region.
 
@@ -43,11 +44,13 @@ MFMA_PER_PRODUCT = {"f32": 1, "f16x3": 3, "bf16x3": 3, "bf16": 1}
 ARCHS = {
     "arch_mdm": dict(latent_dim=256, ff_size=1024, num_layers=8, num_heads=4),
     "arch_mdm_l": dict(latent_dim=512, ff_size=2048, num_layers=8, num_heads=4),
+    "arch_refine": dict(latent_dim=256, ff_size=1024, num_layers=8, num_heads=4),  # MF-MDM R trunk (--config 4 only)
 }
 # --config presets: BASELINE.json configs[] (1-based numbering as in the task text: config 2 = configs[1])
 CONFIGS = {
     2: dict(batch=64, dtype=None, label="BASELINE.json configs[1]: arch_mdm_l B=64 T=196 1000-step DDPM on 1 GPU"),
     3: dict(batch=32, dtype=None, label="BASELINE.json configs[2]: arch_mdm_l B=256 T=196 1000-step DDPM sharded over 8 GPUs (32 clips per GPU)"),
+    4: dict(batch=64, dtype=None, label="BASELINE.json configs[3]: arch_refine (MF-MDM R) trunk B=64 T=196, one forward per step on cached G samples + h2o distances resident in HBM"),
     5: dict(batch=64, dtype="bf16", label="BASELINE.json configs[4]: arch_mdm_l bf16 B=512 T=196 hipGraph 1000-step loop over 8 GPUs (64 clips per GPU)"),
 }
 DEFAULT_DTYPE = "f16x3"  # = oakink2_tamf_amd.hip_backend.DEFAULT_PRECISION (asserted in main): one default everywhere
@@ -395,8 +398,8 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=10.0):
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3 reverse loops; --config 4: 200 forwards)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 1; --config 4: 20)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json workload preset")
     ap.add_argument("--dtype", default=os.environ.get("TAMF_BENCH_DTYPE"), choices=list(PEAK_TFLOPS))
     ap.add_argument("--arch", default="arch_mdm_l", choices=list(ARCHS))
@@ -417,6 +420,14 @@ def parse_args(argv):
     if args.sampler and args.backend != "gloo":
         ap.error("--sampler is the CPU test hook of the launch / gather path: it needs --backend gloo")
     preset = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 200 if args.config == 4 else 3
+    if args.warmup is None:
+        args.warmup = 20 if args.config == 4 else 1
+    if args.config == 4:
+        args.arch = "arch_refine"
+    elif args.arch == "arch_refine":
+        ap.error("arch_refine is the R trunk: use --config 4")
     if args.batch is None:
         args.batch = preset["batch"]
     if args.dtype is None:
@@ -424,6 +435,144 @@ def parse_args(argv):
     if args.also is None:
         args.also = ",".join(d for d in PEAK_TFLOPS if d != args.dtype)
     return args
+
+
+def main_refine(args, dev, ptrace):
+    """--config 4 = BASELINE.json configs[3]: the arch_refine (MF-MDM R) trunk, B = 64, T = 196, ONE forward per step
+    (reference model/segment_refine_model.py:175-217 as launch/sample_refine.py:236-238 calls it), inputs - the cached G samples, the
+    hand->object distances, the conditioning - resident in HBM.  The conditioning precompute (tamf_set_cond) is inside the step, as in
+    the G bench.  value = refined frames/s; ms_per_step = ms per batch (tiny and latency-dominated, reported as such)."""
+    import torch
+
+    from oakink2_tamf_amd.hip_backend import TamfContext
+    from oakink2_tamf_amd.model.segment_refine_model import SegmentRefineModel
+
+    arch = ARCHS["arch_refine"]
+    B, T = args.batch, args.frames
+    # random-init weights of the named architecture (PyTorch default initialisers, fixed seed), synthetic inputs of the config's shape
+    torch.manual_seed(0)
+    sd = {k: v for k, v in SegmentRefineModel(None, **arch).state_dict().items()}
+    cond = {k: v for k, v in synthetic_cond(B, T, seed=1000, nobj=2).items() if k != "text_embedding"}
+    g = torch.Generator().manual_seed(77)
+    x_in = torch.randn(B, T, 99, generator=g).to(dev)
+    h2o = (torch.randn(B, T, 778, generator=g).abs() * 0.05).to(dev)
+    cond_dev = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in cond.items()}
+    n_check = max(0, min(args.check_clips, B))
+    ref = None
+    if n_check or not args.no_cpu_baseline:  # the checker / CPU baseline: the only use of oracle/ here
+        from oracle import mdm_oracle as O
+
+        oarch = O.ARCH_REFINE
+    if n_check:
+        sub = {k: (v[:n_check] if not isinstance(v, list) else v[:n_check]) for k, v in cond.items()}
+        with torch.no_grad():
+            ref = O.refine_forward(sd, oarch, x_in[:n_check].cpu(), h2o[:n_check].cpu(), sub)
+
+    def run_mode(dt, steps, warmup):
+        ctx = TamfContext(arch, B, T, precision=dt, device=dev, kind="R")
+        ctx.load_state_dict(sd)
+
+        def fwd():
+            ctx.set_cond(None, cond_dev["hand_side"], cond_dev["shape"], cond_dev["obj_embedding"], cond_dev["obj_traj"])
+            return ctx.refine(x_in, h2o)
+
+        for _ in range(warmup):
+            out = fwd()
+        torch.cuda.synchronize(dev)
+        t0, w0 = time.perf_counter(), time.time()
+        for _ in range(steps):
+            out = fwd()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        w1 = time.time()
+        flag = bool(ctx.status_flags(clear=True) & 1) if dt == "f16x3" else False
+        err = float((out[:n_check].cpu() - ref).abs().max()) if ref is not None else None
+        agg, reps = {}, 5
+        for r in range(reps + 1):
+            rows = ctx.refine_profile(x_in, h2o)
+            if r:
+                for name, ms, fl in rows:
+                    a = agg.setdefault(name, [0.0, 0.0, 0])
+                    a[0], a[1], a[2] = a[0] + ms, a[1] + fl, a[2] + 1
+        fwd_flops = sum(a[1] for a in agg.values()) / reps
+        prof = [{"kernel": n, "launches_per_forward": a[2] // reps, "avg_ms": a[0] / a[2], "algorithmic_gflop_per_launch": a[1] / a[2] / 1e9,
+                 "tflops": (a[1] / a[2]) / (a[0] / a[2] * 1e-3) / 1e12 if a[0] > 0 else 0.0, "share": a[0] / sum(x[0] for x in agg.values())}
+                for n, a in sorted(agg.items(), key=lambda kv: -kv[1][0])]
+        finite = bool(torch.isfinite(out).all().item())
+        ctx.close()
+        return {"elapsed": el, "wall": (w0, w1), "err": err, "flag": flag, "finite": finite, "profile": prof, "forward_gflop": fwd_flops / 1e9}
+
+    head = run_mode(args.dtype, args.steps, args.warmup)
+    power = None
+    if ptrace is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if hasattr(pr, "pci_bus_id") else None
+        power = ptrace.finish(head["wall"][0], head["wall"][1], pci)
+    peak = PEAK_TFLOPS[args.dtype]
+    dom = head["profile"][0]
+    ms_batch = head["elapsed"] / args.steps * 1e3
+    whole_tf = head["forward_gflop"] * 1e9 / (ms_batch * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "dtype": args.dtype, "mfma_per_product": MFMA_PER_PRODUCT[args.dtype],
+                "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": None,
+                "avg_launch_ms": dom["avg_ms"], "share_of_step": dom["share"], "forward_algorithmic_gflop": head["forward_gflop"],
+                "launches_per_forward": sum(r["launches_per_forward"] for r in head["profile"]),
+                "note": "a 1.2-ms forward of 50 launches over 12 736 token rows of width 256: launch ramps and epilogues, not a roofline, bound it (SURVEY.md 8d)"}
+    check = {args.dtype: head["err"]} if head["err"] is not None else {}
+    finite_by, range_flags = {args.dtype: head["finite"]}, ({args.dtype: head["flag"]} if args.dtype == "f16x3" else {})
+    other = {}
+    for dt in [d for d in args.also.split(",") if d and d != args.dtype]:
+        r = run_mode(dt, max(20, args.steps // 4), 5)
+        ms = r["elapsed"] / max(20, args.steps // 4) * 1e3
+        other[dt] = {"value": B * T / ms * 1e3, "unit": "frames/s", "ms_per_batch": ms, "finite": r["finite"],
+                     "whole_path_tflops": r["forward_gflop"] / ms / 1e3, "whole_path_frac_of_peak": r["forward_gflop"] / ms / 1e3 / PEAK_TFLOPS[dt],
+                     "dominant_kernel": r["profile"][0]["kernel"], "dominant_kernel_frac": r["profile"][0]["tflops"] / PEAK_TFLOPS[dt]}
+        finite_by[dt] = r["finite"]
+        if r["err"] is not None:
+            check[dt] = r["err"]
+        if dt == "f16x3":
+            range_flags[dt] = r["flag"]
+    if "f32" in other:
+        roofline["f32_value"], roofline["f32_ms_per_batch"] = other["f32"]["value"], other["f32"]["ms_per_batch"]
+        roofline["f32_whole_path_frac"] = other["f32"]["whole_path_frac_of_peak"]
+    line = {
+        "metric": "refined motion frames/s (arch_refine trunk, one forward per batch)", "value": B * T * args.steps / head["elapsed"],
+        "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_batch, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic (random-init weights of arch_refine, N(0,1) G samples, |N(0, 5 cm)| hand->object distances, N(0,1) conditioning)",
+        "config": {"workload": f"arch_refine trunk B={B} T={T}, one forward per step ({CONFIGS[4]['label']})", "preset": 4, "clips_per_gpu": B,
+                   "frames": T, "parallelism": "single GPU"},
+        "ms_per_batch": ms_batch, "whole_path_tflops": whole_tf, "whole_path_frac_of_peak": whole_tf / peak, "finite": head["finite"],
+        "roofline": roofline, "kernels": head["profile"][:8],
+    }
+    if power is not None:
+        line["power"] = power
+    if check:
+        line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
+                         "what": f"refine_pose_repr of the first {n_check} clips of the bench batch vs oracle.refine_forward (fp32 torch-CPU restatement of the reference)"}
+    if range_flags:
+        line["f16_range_flag"] = range_flags
+    line["finite_by_dtype"] = finite_by
+    line["check_ok"] = checks_ok(finite_by, range_flags, check)
+    if other:
+        line["other_dtypes"] = other
+    if not args.no_cpu_baseline:
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        times = []
+        with torch.no_grad():
+            for it in range(4):
+                t0 = time.perf_counter()
+                O.refine_forward(sd, oarch, x_in.cpu(), h2o.cpu(), cond)
+                times.append(time.perf_counter() - t0)
+        fs = sum(times[1:]) / 3
+        line["cpu_baseline"] = {"value": B * T / fs, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+                                "sample": f"{B} clips x T={T}: 3 timed oracle.refine_forward calls after 1 warm-up ({fs * 1e3:.0f} ms per batch)"}
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line), flush=True)
+    if not line["check_ok"]:
+        print("bench.py: in-run check FAILED (see check / finite_by_dtype / f16_range_flag in the line)", file=sys.stderr, flush=True)
+        return 3
+    return 0
 
 
 def main(argv=None, sampler_factory=None):
@@ -477,6 +626,10 @@ def main(argv=None, sampler_factory=None):
     from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
     from oakink2_tamf_amd.model.interaction_segment_mdm import InterationSegmentMDM
 
+    if args.config == 4:
+        if world != 1 or stub:
+            raise SystemExit("--config 4 (the R trunk, one forward per step) is a single-GPU measurement")
+        return main_refine(args, dev, ptrace)
     factory = sampler_factory or HipSampler
     rc = 0
     if not stub:
@@ -552,7 +705,18 @@ def main(argv=None, sampler_factory=None):
         range_flags[args.dtype] = flag_any
     # what every rank sampled, as seen by the collective (printed by rank 0)
     rank_info = {"rank": rank, "clips": [clip0, clip0 + B], "device": str(dev), "f16_range_flag": my_flag,
-                 "finite": bool(torch.isfinite(out).all().item())}
+                 "finite": bool(torch.isfinite(out).all().item()), "pid": os.getpid(), "local_rank": local_rank}
+    if dev.type == "cuda":  # which physical GPU this rank really drove, and the collective library it spoke through
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            rank_info["pci"] = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            rank_info["gpu"] = pr.name
+        except (AttributeError, RuntimeError):
+            rank_info["pci"] = None
+        try:
+            rank_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001  (a torch build without the binding: the line simply lacks the field)
+            rank_info["rccl_version"] = None
     if world > 1:
         infos = [None] * world
         dist.all_gather_object(infos, rank_info)
@@ -734,6 +898,19 @@ def main(argv=None, sampler_factory=None):
                 "kernel": fr.get("kernel"), "achieved": fr.get("achieved"), "peak": fr.get("peak"), "frac": fr.get("frac"),
                 "attention_frac": (fr.get("attention") or {}).get("frac"),
                 "what": "the same workload in the reference's own arithmetic (exact fp32 MFMA products, fp32 accumulate)"}
+        # ... and once more as FLAT SCALARS of `roofline` (a parser that keeps only scalar members of the contract's objects - the round-4
+        # driver did - still carries the credited strict-fp32 number beside the fp32-tolerance headline)
+        if roofline is not None:
+            roofline["attention_frac"] = (roofline.get("attention") or {}).get("frac")
+            roofline["mfma_sustained_tflops"] = (roofline.get("mfma_sustained") or {}).get("value")
+            if "fp32" in line:
+                fr = line["fp32"].get("roofline") or {}
+                roofline["f32_value"] = line["fp32"]["value"]
+                roofline["f32_ms_per_ddpm_step"] = line["fp32"]["ms_per_ddpm_step"]
+                roofline["f32_frac"] = fr.get("frac")
+                roofline["f32_whole_path_frac"] = line["fp32"].get("whole_path_frac_of_peak")
+                roofline["f32_attention_frac"] = (fr.get("attention") or {}).get("frac")
+                roofline["f32_kernel"] = fr.get("kernel")
         if power is not None:
             # (rank 0's GPU; every rank runs its own clips through the same number of DDPM steps in ms_per_ddpm_step)
             power["joules_per_ddpm_step_per_gpu"] = power["watts"] * line["ms_per_ddpm_step"] * 1e-3 if power.get("watts") else None

@@ -83,6 +83,12 @@ typedef struct tamf_arch {
 /* Create a context on `device` able to run up to max_batch clips of up to max_frames frames. */
 int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames, int32_t precision,
                     int32_t device, tamf_ctx** out);
+/* Re-dimension the context for up to max_batch clips of up to max_frames frames: the workspaces (sampler state, token rows, operand
+ * planes, scratch) are freed and allocated anew; weights, tables and the schedule stay, so no checkpoint is uploaded or repacked again
+ * (a launcher whose clip source changes shape, launch/sample.py:204-215 / launch/sample_refine.py:224-236, pays milliseconds).
+ * Synchronises the device, drops the captured hipGraph and the conditioning (tamf_set_cond must be called again) and clears the
+ * context's status word.  On failure the context can only be destroyed. */
+int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_frames);
 void tamf_ctx_destroy(tamf_ctx* ctx);
 const char* tamf_last_error(const tamf_ctx* ctx);
 
@@ -110,6 +116,15 @@ int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* posterior_me
 int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const float* text_emb_dev,
                   const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
                   const float* obj_traj_dev, void* stream);
+
+/* The same with per-clip object counts (host, (B,) int32, each in [1, nobj]; NULL = tamf_set_cond): the two object means of the
+ * forward (interaction_segment_mdm.py:233-263) run over clip b's first obj_num[b] objects instead of all nobj rows of the zero-padded
+ * batch.  That is what the reference's launchers compute - they call the model one clip at a time (launch/sample.py:206,
+ * launch/sample_refine.py:228), so a clip never sees another clip's padding - and what a batched launcher must pass to reproduce them
+ * (dataset/collate.py:43-56 pads `obj_traj` / `obj_embedding` to the batch maximum and carries `obj_num`). */
+int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const int32_t* obj_num_host, const float* text_emb_dev,
+                         const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
+                         const float* obj_traj_dev, void* stream);
 
 /* x0_hat = G(x_t, t | cond).  x_dev, x0_out_dev: (B, input_dim, 1, T) f32; t_dev: (B,) int64 device
  * (values in [0, max_timesteps)). */
@@ -205,6 +220,10 @@ int tamf_loop_stats(const tamf_ctx* ctx, int32_t* graph_captures, int32_t* graph
  * milliseconds, the algorithmic FLOPs of the reference work it stands for, and a name
  * (names_host: max_n x 48 chars).  Returns the number of launches (>= 0) or a negative tamf_status. */
 int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host, void* stream);
+/* The same for ONE tamf_refine call of an R context (arguments of tamf_refine, then those of tamf_step_profile); the first
+ * interval also holds the input-packing kernel of the call. */
+int tamf_refine_profile(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev, int32_t max_n,
+                        float* ms_host, double* flops_host, char* names_host, void* stream);
 
 /* ---- kernel-level test hooks (used by tests/ only; same kernels the step uses) ------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, optional activation (0 none, 1 silu, 2 gelu_erf); all f32 device buffers;
@@ -218,6 +237,17 @@ int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const 
 /* out[b,s,h*hd+e] = softmax(q k^T / sqrt(hd)) v per (b,h); qkv_dev: (B, S, 3*H*hd) f32 packed [q|k|v]. */
 int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
                         float* out_dev, void* stream);
+/* Guard bands (the out-of-bounds check that stands in for GPU AddressSanitizer, which gfx950 lacks here).  After
+ * tamf_test_set_guard_bytes(n) - n a multiple of 256, 0 switches it off - every device allocation of contexts created by THIS process
+ * from then on (activations, operand planes, V^T, scratch, weights, tables) is n bytes longer at both ends and the margins hold a
+ * pattern.  tamf_test_check_guards synchronises the device and verifies all margins of `ctx`: 0 if intact, TAMF_ERR_STATE with the
+ * offending allocations (creation expression, byte offsets) in tamf_last_error otherwise; *n_checked (may be NULL) = number of guarded
+ * allocations.  Test hooks: no product path calls them. */
+int tamf_test_set_guard_bytes(int64_t bytes);
+int tamf_test_check_guards(tamf_ctx* ctx, int32_t* n_checked);
+/* The checker's own test: zero nbytes at `offset` from the start of guarded allocation #alloc_index (negative / beyond-the-end offsets
+ * reach into its margins). */
+int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset, int32_t nbytes);
 /* Philox normal draws exactly as the sampling loop generates them: out (B, n_feat, 1, T). */
 int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
                      float* out_dev, void* stream);

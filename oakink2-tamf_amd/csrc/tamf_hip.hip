@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,20 @@ struct GraphKey {
   }
 };
 
+// Guard-band mode, for tests only (GPU AddressSanitizer is not available for gfx950 here): with tamf_test_set_guard_bytes(n > 0) every
+// device allocation of contexts created afterwards is n bytes longer at both ends, the margins are filled with GUARD_BYTE, and
+// tamf_test_check_guards() verifies them - a kernel that stores below or beyond its buffer (the V^T overrun of round 4) changes a margin
+// instead of a neighbouring live buffer, where a later kernel would have overwritten the evidence.
+struct GuardRec {
+  char* base;
+  size_t bytes, guard;
+  const char* tag;
+  bool ws;
+};
+static constexpr unsigned char GUARD_BYTE = 0xA5;
+static std::atomic<size_t> g_guard_bytes{0};
+static thread_local const char* g_alloc_tag = "";
+
 struct tamf_ctx {
   tamf_arch arch{};
   int prec = 0, device = 0, Bmax = 0, Tmax = 0;
@@ -65,7 +80,10 @@ struct tamf_ctx {
   int XN = 128; // padded N of the output head
   int EB = 4;  // bytes per logical operand element (f32 4, bf16 2, bf16x3 4 = hi + lo)
   std::string err;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;     // weights, tables, schedule: live as long as the context
+  std::vector<void*> ws_allocs;  // workspaces dimensioned by (max_batch, max_frames): re-made by tamf_ctx_resize
+  bool alloc_ws = false;         // dev_alloc files its allocation under ws_allocs
+  std::vector<GuardRec> guards;  // guard-band mode (tamf_test_set_guard_bytes): one record per allocation
   std::map<std::string, std::vector<float>> raw;
   std::map<std::string, std::vector<int64_t>> raw_shape;
   bool finalized = false, cond_set = false;
@@ -98,6 +116,7 @@ struct tamf_ctx {
   int* tcur = nullptr;
   unsigned* status = nullptr;  // this context's sticky status word (tamf_device.h): written by its kernels only
   unsigned char* side_dev = nullptr;
+  int* objnum_dev = nullptr;  // per-clip object counts of tamf_set_cond_ragged
   // graph
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
@@ -146,9 +165,17 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static int dev_alloc(tamf_ctx* ctx, void** p, size_t bytes, bool zero = false) {
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(p, bytes);
+  const size_t guard = g_guard_bytes.load();
+  hipError_t e = hipMalloc(p, bytes + 2 * guard);
   if (e != hipSuccess) return fail(ctx, TAMF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
-  ctx->allocs.push_back(*p);
+  (ctx->alloc_ws ? ctx->ws_allocs : ctx->allocs).push_back(*p);
+  if (guard) {
+    char* base = (char*)*p;
+    HIPCHK(ctx, hipMemset(base, GUARD_BYTE, guard));
+    HIPCHK(ctx, hipMemset(base + guard + bytes, GUARD_BYTE, guard));
+    ctx->guards.push_back(GuardRec{base, bytes, guard, g_alloc_tag, ctx->alloc_ws});
+    *p = base + guard;
+  }
   if (zero) HIPCHK(ctx, hipMemset(*p, 0, bytes));
   return 0;
 }
@@ -602,6 +629,62 @@ static int alloc_operand(tamf_ctx* ctx, OperandBuf* ob, long elems, bool zero = 
   return dev_alloc(ctx, &ob->p, (size_t)elems * ctx->EB, zero);
 }
 
+// the kernels address operands with 32-bit byte offsets and int element indices: refuse shapes beyond them
+static int check_dims(const tamf_arch* arch, int max_batch, int max_frames) {
+  if (max_batch <= 0 || max_frames <= 0 || max_frames > 4990) return fail(nullptr, TAMF_ERR_INVALID, "bad max_batch/max_frames");
+  const long long sp = (max_frames + 5 + 7) / 8 * 8, mmax = (long long)max_batch * sp;
+  const long long widest = std::max<long long>(arch->ff_size, 3LL * arch->latent_dim);
+  if (mmax * widest * 4 >= (1LL << 32) || (long long)max_batch * max_frames * 896 * 4 >= (1LL << 32))
+    return fail(nullptr, TAMF_ERR_INVALID, "max_batch x max_frames too large for one context (32-bit operand offsets): split the batch");
+  return 0;
+}
+
+// every buffer whose size depends on (max_batch, max_frames): sampler state, token rows, operand planes, V^T, scratch
+static int alloc_workspaces(tamf_ctx* ctx, int max_batch, int max_frames) {
+  const int d = ctx->d;
+  const int Smax = max_frames + ctx->P, Spmax = round_up(Smax, 8), Skpmax = round_up(Smax > 208 ? Smax : 208, 32);  // (>= vt_row_keys of every shape)
+  const long BT = (long)max_batch * max_frames;
+  const long Mmax = (long)max_batch * Spmax;
+  ctx->Mmax = Mmax;
+  ctx->Bmax = max_batch;
+  ctx->Tmax = max_frames;
+  ctx->alloc_ws = true;
+  int rc = 0;
+#define A(call)             \
+  do {                      \
+    g_alloc_tag = #call;    \
+    if (rc == 0) rc = call; \
+  } while (0)
+  A(dev_alloc(ctx, (void**)&ctx->xs, BT * ctx->XK * 4, true));
+  if (ctx->prec == TAMF_PREC_F32) ctx->xs_op.p = ctx->xs;
+  else { A(alloc_operand(ctx, &ctx->xs_op, BT * ctx->XK, true)); ctx->xs_st = ctx->xs_op.p; }
+  A(dev_alloc(ctx, (void**)&ctx->cobj, BT * d * 4));
+  A(alloc_operand(ctx, &ctx->h1_op, BT * d));
+  A(dev_alloc(ctx, (void**)&ctx->X, Mmax * d * 4, true));
+  if (ctx->prec == TAMF_PREC_F32) ctx->X_op.p = ctx->X;
+  else { A(alloc_operand(ctx, &ctx->X_op, Mmax * d, true)); ctx->X_st = ctx->X_op.p; }
+  A(alloc_operand(ctx, &ctx->QK_op, Mmax * 2 * d, true));
+  A(alloc_operand(ctx, &ctx->Vt_op, (long)max_batch * d * Skpmax, true));
+  A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
+  A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
+  A(dev_alloc(ctx, (void**)&ctx->tmp32, Mmax * d * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
+  const long meansz = std::max<long>((long)max_batch * std::max(ctx->arch.obj_embed_dim, ctx->arch.hand_shape_dim),
+                                     BT * ctx->arch.obj_input_dim);
+  A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
+  A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
+  A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
+  A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
+  A(dev_alloc(ctx, (void**)&ctx->objnum_dev, (long)max_batch * 4, true));
+  A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
+#undef A
+  g_alloc_tag = "(weights / tables)";
+  ctx->alloc_ws = false;
+  return rc;
+}
+
 extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames, int32_t precision,
                                int32_t device, tamf_ctx** out) {
   if (!arch || !out) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
@@ -616,7 +699,6 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (arch->input_dim <= 0 || arch->input_dim > 128) return fail(nullptr, TAMF_ERR_INVALID, "input_dim must be in [1,128]");
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
   if (arch->kind != TAMF_KIND_G && arch->kind != TAMF_KIND_R) return fail(nullptr, TAMF_ERR_INVALID, "unknown model kind");
-  if (max_batch <= 0 || max_frames <= 0 || max_frames > 4990) return fail(nullptr, TAMF_ERR_INVALID, "bad max_batch/max_frames");
   int ndev = 0;
   hipError_t de = hipGetDeviceCount(&ndev);
   if (de != hipSuccess || ndev <= 0)
@@ -624,13 +706,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
                                            "): libtamf_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(nullptr, TAMF_ERR_INVALID, "device index out of range");
 
-  {
-    // the kernels address operands with 32-bit byte offsets and int element indices: refuse shapes beyond them
-    const long long sp = (max_frames + 5 + 7) / 8 * 8, mmax = (long long)max_batch * sp;
-    const long long widest = std::max<long long>(arch->ff_size, 3LL * d);
-    if (mmax * widest * 4 >= (1LL << 32) || (long long)max_batch * max_frames * 896 * 4 >= (1LL << 32))
-      return fail(nullptr, TAMF_ERR_INVALID, "max_batch x max_frames too large for one context (32-bit operand offsets): split the batch");
-  }
+  if (int rc = check_dims(arch, max_batch, max_frames)) return rc;
   tamf_ctx* ctx = new tamf_ctx();
   ctx->arch = *arch;
   ctx->prec = precision;
@@ -660,43 +736,18 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_wg_slots = 2 * cus;
   }
-  hipError_t pe = prepare_all<OpF32>();
-  if (pe == hipSuccess && precision != TAMF_PREC_F32) TAMF_WITH_OP(precision, pe = prepare_all<Op>());
+  hipError_t pe;
+  {
+    TAMF_LAUNCH_LOCK;  // prepare() keeps unsynchronised per-device "done" flags that locked launches read
+    pe = prepare_all<OpF32>();
+    if (pe == hipSuccess && precision != TAMF_PREC_F32) TAMF_WITH_OP(precision, pe = prepare_all<Op>());
+  }
   if (pe != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, std::string("kernel attribute setup failed: ") + hipGetErrorString(pe)));
   if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, "hipStreamCreate failed"));
 
-  const int Smax = max_frames + ctx->P, Spmax = round_up(Smax, 8), Skpmax = round_up(Smax > 208 ? Smax : 208, 32);  // (>= vt_row_keys of every shape)
-  const long BT = (long)max_batch * max_frames;
-  const long Mmax = (long)max_batch * Spmax;
-  ctx->Mmax = Mmax;
-  int rc = 0;
-  auto A = [&](int r) { if (rc == 0) rc = r; };
-  A(dev_alloc(ctx, (void**)&ctx->xs, BT * ctx->XK * 4, true));
-  if (precision == TAMF_PREC_F32) ctx->xs_op.p = ctx->xs;
-  else { A(alloc_operand(ctx, &ctx->xs_op, BT * ctx->XK, true)); ctx->xs_st = ctx->xs_op.p; }
-  A(dev_alloc(ctx, (void**)&ctx->cobj, BT * d * 4));
-  A(alloc_operand(ctx, &ctx->h1_op, BT * d));
-  A(dev_alloc(ctx, (void**)&ctx->X, Mmax * d * 4, true));
-  if (precision == TAMF_PREC_F32) ctx->X_op.p = ctx->X;
-  else { A(alloc_operand(ctx, &ctx->X_op, Mmax * d, true)); ctx->X_st = ctx->X_op.p; }
-  A(alloc_operand(ctx, &ctx->QK_op, Mmax * 2 * d, true));
-  A(alloc_operand(ctx, &ctx->Vt_op, (long)max_batch * d * Skpmax, true));
-  A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
-  A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
-  A(dev_alloc(ctx, (void**)&ctx->tmp32, Mmax * d * 4, true));
-  A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
-  A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
-  const long meansz = std::max<long>((long)max_batch * std::max(arch->obj_embed_dim, arch->hand_shape_dim),
-                                     BT * arch->obj_input_dim);
-  A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
-  A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
-  A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
-  A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
-  A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
-  A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
-  if (rc) return bail(rc);
+  if (int rc = alloc_workspaces(ctx, max_batch, max_frames)) return bail(rc);
   if (hipEventCreateWithFlags(&ctx->graph_done, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, TAMF_ERR_HIP, "hipEventCreate failed"));
   {
@@ -721,7 +772,33 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   for (void* p : ctx->allocs) (void)hipFree(p);
+  for (void* p : ctx->ws_allocs) (void)hipFree(p);
   delete ctx;
+}
+
+static int retire_graph(tamf_ctx* ctx);
+
+extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_frames) {
+  TAMF_LAUNCH_LOCK;
+  if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
+  if (int rc = check_dims(&ctx->arch, max_batch, max_frames)) {
+    ctx->err = g_noctx_err;
+    return rc;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  TRY(retire_graph(ctx));
+  if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+  ctx->graph_key = GraphKey{};
+  for (void* p : ctx->ws_allocs) (void)hipFree(p);
+  ctx->ws_allocs.clear();
+  ctx->guards.erase(std::remove_if(ctx->guards.begin(), ctx->guards.end(), [](const GuardRec& g) { return g.ws; }), ctx->guards.end());
+  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = ctx->etmp = ctx->meanbuf = ctx->objfeat = ctx->tmp32 = nullptr;
+  ctx->xs_op = ctx->h1_op = ctx->X_op = ctx->QK_op = ctx->Vt_op = ctx->A_op = ctx->H_op = OperandBuf{};
+  ctx->X_st = ctx->xs_st = nullptr;
+  ctx->cond_set = false;
+  ctx->B = ctx->T = ctx->S = ctx->Sp = ctx->Skp = ctx->M = 0;
+  return alloc_workspaces(ctx, max_batch, max_frames);
 }
 
 // fragment-major copy of a [512][K] operand matrix (tamf_gemm_rowblock.h)
@@ -958,6 +1035,12 @@ extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c
 extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const float* text_emb_dev,
                              const uint8_t* hand_side_host, const float* shape_dev, const float* obj_emb_dev,
                              const float* obj_traj_dev, void* stream) {
+  return tamf_set_cond_ragged(ctx, B, T, nobj, nullptr, text_emb_dev, hand_side_host, shape_dev, obj_emb_dev, obj_traj_dev, stream);
+}
+
+extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, const int32_t* obj_num_host,
+                                    const float* text_emb_dev, const uint8_t* hand_side_host, const float* shape_dev,
+                                    const float* obj_emb_dev, const float* obj_traj_dev, void* stream) {
   TAMF_LAUNCH_LOCK;
   if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
   if (!ctx->finalized) return fail(ctx, TAMF_ERR_STATE, "weights not finalised");
@@ -966,8 +1049,17 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
     return fail(ctx, TAMF_ERR_INVALID, "null conditioning tensor");
   for (int b = 0; b < B; ++b)
     if (hand_side_host[b] > 1) return fail(ctx, TAMF_ERR_INVALID, "unexpected hand_side: " + std::to_string(hand_side_host[b]));
+  if (obj_num_host)
+    for (int b = 0; b < B; ++b)
+      if (obj_num_host[b] < 1 || obj_num_host[b] > nobj)
+        return fail(ctx, TAMF_ERR_INVALID, "obj_num[" + std::to_string(b) + "] = " + std::to_string(obj_num_host[b]) + " outside [1, nobj]");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  const int* cnt = nullptr;
+  if (obj_num_host) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->objnum_dev, obj_num_host, sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+    cnt = ctx->objnum_dev;
+  }
   const int d = ctx->d, P = ctx->P, ht = ctx->has_t, nrows = P - ht;
   ctx->B = B;
   ctx->T = T;
@@ -990,21 +1082,21 @@ extern "C" int tamf_set_cond(tamf_ctx* ctx, int32_t B, int32_t T, int32_t nobj, 
                      j, ht + j);
   ++j;
   const int sd = ctx->arch.hand_shape_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * sd), dim3(256), 0, st, shape_dev, ctx->meanbuf, B, T, sd);
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * sd), dim3(256), 0, st, shape_dev, ctx->meanbuf, B, T, sd, (const int*)nullptr);
   hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wshape, ctx->bshape,
                      ctx->etmp, (long)B, d, sd);
   hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
                      j, ht + j);
   ++j;
   const int od = ctx->arch.obj_embed_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * od), dim3(256), 0, st, obj_emb_dev, ctx->meanbuf, B, nobj, od);
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * od), dim3(256), 0, st, obj_emb_dev, ctx->meanbuf, B, nobj, od, cnt);
   hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wobj, ctx->bobj,
                      ctx->etmp, (long)B, d, od);
   hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
                      j, ht + j);
   // object half of input_merge.0, hoisted: cobj[b,tau,:] = W_m1[:, d:2d] (W_q mean_o traj + b_q) + fused bias
   const int qd = ctx->arch.obj_input_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd);
+  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd, cnt);
   hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * T * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wq, ctx->bq,
                      ctx->objfeat, (long)B * T, d, qd);
   GemmArgs<OpF32> ga{ctx->objfeat, d, (const float*)ctx->Wm1b_f32.p, d, B * T, d, d, 0};
@@ -1367,6 +1459,56 @@ extern "C" int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t cle
   return 0;
 }
 
+extern "C" int tamf_test_set_guard_bytes(int64_t bytes) {
+  if (bytes < 0 || bytes > (1 << 20) || bytes % 256) return fail(nullptr, TAMF_ERR_INVALID, "guard bytes must be a multiple of 256 in [0, 1 MiB]");
+  g_guard_bytes.store((size_t)bytes);
+  return 0;
+}
+
+extern "C" int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset, int32_t nbytes) {
+  if (!ctx || alloc_index < 0 || (size_t)alloc_index >= ctx->guards.size() || nbytes <= 0) return fail(ctx, TAMF_ERR_INVALID, "bad argument");
+  const GuardRec& g = ctx->guards[alloc_index];
+  if (offset < -(int64_t)g.guard || offset + nbytes > (int64_t)(g.bytes + g.guard)) return fail(ctx, TAMF_ERR_INVALID, "outside the allocation and its margins");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemset(g.base + g.guard + offset, 0, nbytes));
+  return 0;
+}
+
+extern "C" int tamf_test_check_guards(tamf_ctx* ctx, int32_t* n_checked) {
+  if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  if (n_checked) *n_checked = (int32_t)ctx->guards.size();
+  std::vector<unsigned char> host;
+  int bad = 0;
+  std::string report;
+  for (size_t i = 0; i < ctx->guards.size(); ++i) {
+    const GuardRec& g = ctx->guards[i];
+    host.resize(g.guard);
+    for (int side = 0; side < 2; ++side) {
+      const char* src = side ? g.base + g.guard + g.bytes : g.base;
+      HIPCHK(ctx, hipMemcpy(host.data(), src, g.guard, hipMemcpyDeviceToHost));
+      size_t first = g.guard, last = 0, n = 0;
+      for (size_t k = 0; k < g.guard; ++k)
+        if (host[k] != GUARD_BYTE) {
+          if (first == g.guard) first = k;
+          last = k;
+          ++n;
+        }
+      if (n) {
+        ++bad;
+        if (report.size() < 1500)
+          report += std::string(report.empty() ? "" : "; ") + "allocation #" + std::to_string(i) + " [" + g.tag + "] of " +
+                    std::to_string(g.bytes) + " bytes: " + std::to_string(n) + " bytes written " +
+                    (side ? "BEYOND its end (offsets +" + std::to_string(first) + " .. +" + std::to_string(last) + ")"
+                          : "BELOW its start (offsets -" + std::to_string(g.guard - first) + " .. -" + std::to_string(g.guard - last) + ")");
+      }
+    }
+  }
+  if (bad) return fail(ctx, TAMF_ERR_STATE, "out-of-bounds device stores: " + report);
+  return 0;
+}
+
 extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
 
 extern "C" int tamf_loop_stats(const tamf_ctx* ctx, int32_t* graph_captures, int32_t* graph_launches_last_loop) {
@@ -1384,14 +1526,10 @@ static int profile_impl(tamf_ctx* ctx, hipStream_t st) {
   return enqueue_step<Op>(ctx, st, h);
 }
 
-extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host,
-                                 void* stream) {
-  TAMF_LAUNCH_LOCK;
-  if (!ctx || !ms_host || !flops_host || !names_host || max_n <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
-  if (!ctx->cond_set || ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "conditioning / schedule not set");
-  if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "needs a G context");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)stream;
+// Runs `body` (which enqueues launches through enqueue_step) with an event behind every launch and reports per launch: milliseconds,
+// algorithmic FLOPs, name.
+template <class Body>
+static int profile_run(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host, hipStream_t st, Body body) {
   ctx->prof_ev.clear();
   ctx->prof_names.clear();
   ctx->prof_flops.clear();
@@ -1402,11 +1540,9 @@ extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, d
   hipEvent_t cal[6];
   for (hipEvent_t& e : cal) HIPCHK(ctx, hipEventCreate(&e));
   ctx->prof_on = true;
-  int rc;
-  hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B, ctx->n_t > 0 ? ctx->n_t : 1);
   for (hipEvent_t& e : cal) (void)hipEventRecord(e, st);
   (void)hipEventRecord(ev0, st);
-  TAMF_WITH_OP(ctx->prec, rc = profile_impl<Op>(ctx, st));
+  int rc = body();
   ctx->prof_on = false;
   hipError_t se = hipStreamSynchronize(st);
   int n = 0;
@@ -1436,6 +1572,38 @@ extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, d
   if (rc) return rc;
   HIPCHK(ctx, se);
   return n;
+}
+
+extern "C" int tamf_step_profile(tamf_ctx* ctx, int32_t max_n, float* ms_host, double* flops_host, char* names_host,
+                                 void* stream) {
+  TAMF_LAUNCH_LOCK;
+  if (!ctx || !ms_host || !flops_host || !names_host || max_n <= 0) return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  if (!ctx->cond_set || ctx->n_steps <= 0) return fail(ctx, TAMF_ERR_STATE, "conditioning / schedule not set");
+  if (ctx->arch.kind != TAMF_KIND_G) return fail(ctx, TAMF_ERR_STATE, "needs a G context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_t_kernel, grid1d(ctx->B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, ctx->n_steps / 2, ctx->B, ctx->n_t > 0 ? ctx->n_t : 1);
+  return profile_run(ctx, max_n, ms_host, flops_host, names_host, st, [&]() {
+    int rc = 0;
+    TAMF_WITH_OP(ctx->prec, rc = profile_impl<Op>(ctx, st));
+    return rc;
+  });
+}
+
+extern "C" int tamf_refine_profile(tamf_ctx* ctx, const float* sample_pose_repr_dev, const float* h2o_dist_dev, float* out_dev,
+                                   int32_t max_n, float* ms_host, double* flops_host, char* names_host, void* stream) {
+  TAMF_LAUNCH_LOCK;
+  if (!ctx || !sample_pose_repr_dev || !h2o_dist_dev || !out_dev || !ms_host || !flops_host || !names_host || max_n <= 0)
+    return fail(ctx, TAMF_ERR_INVALID, "null/invalid argument");
+  if (!ctx->cond_set) return fail(ctx, TAMF_ERR_STATE, "conditioning not set");
+  if (ctx->arch.kind != TAMF_KIND_R) return fail(ctx, TAMF_ERR_STATE, "tamf_refine_profile needs an R context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  return profile_run(ctx, max_n, ms_host, flops_host, names_host, st, [&]() {
+    int rc = 0;
+    TAMF_WITH_OP(ctx->prec, rc = refine_impl<Op>(ctx, sample_pose_repr_dev, h2o_dist_dev, out_dev, st));
+    return rc;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -196,15 +196,18 @@ __global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float
   }
 }
 
-// out[o][i] = mean_m in[o][m][i]   (torch.mean: sum / n)
-__global__ void mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int outer, int nmid, int inner) {
+// out[o][i] = mean_m in[o][m][i]   (torch.mean: sum / n); with `cnt` the mean of outer index o runs over its first
+// clamp(cnt[o], 1, nmid) middle entries only (per-clip object counts of a zero-padded batch, tamf_set_cond_ragged)
+__global__ void mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int outer, int nmid, int inner,
+                                const int* __restrict__ cnt) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)outer * inner) return;
   const int i = (int)(idx % inner);
   const long o = idx / inner;
+  const int n = cnt ? max(1, min(cnt[o], nmid)) : nmid;
   float s = 0.f;
-  for (int m = 0; m < nmid; ++m) s += in[(o * nmid + m) * inner + i];
-  out[idx] = s / (float)nmid;
+  for (int m = 0; m < n; ++m) s += in[(o * nmid + m) * inner + i];
+  out[idx] = s / (float)n;
 }
 
 // out[r][n] = sum_k in[r][k] * W[n][k] + bias[n]  (tiny K; one thread per output)

@@ -27,8 +27,10 @@ def kernels(path):
         m = re.match(r"^(_Z16clip_gemm_kernelI\w+):", lines[i])
         if m:
             j = i
-            while not lines[j].startswith(".Lfunc_end"):
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
                 j += 1
+            if j >= len(lines):
+                raise IsaMismatch("no .Lfunc_end label behind " + m.group(1) + ": unknown assembly layout")
             yield m.group(1), lines[i:j]
             i = j
         i += 1

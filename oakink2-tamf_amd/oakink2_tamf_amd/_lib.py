@@ -21,12 +21,36 @@ class TamfBuildError(RuntimeError):
     pass
 
 
+STAMP_PATH = LIB_PATH + ".src.sha256"
+
+
+def source_digest() -> str:
+    """sha256 over the kernel sources and the C header (names + contents, sorted): what the built library is stamped with"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(INCLUDE, "tamf_hip.h")]:
+        if os.path.exists(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
+    """The in-tree library is current when the digest of the sources it was built from (written beside it by build()) equals the
+    digest of the sources in the tree.  Content, not mtimes: copying the tree to a GPU box resets every mtime, and eight ranks of a
+    multi-GPU launch must not queue behind a needless 80-second rebuild inside somebody's timed window."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(INCLUDE, "tamf_hip.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().strip() != source_digest()
+    except OSError:
+        # a library without a stamp (built by an older tree): fall back to the mtime rule once; build() writes the stamp
+        t = os.path.getmtime(LIB_PATH)
+        deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(INCLUDE, "tamf_hip.h")]
+        return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -81,7 +105,7 @@ def _build_locked(hipcc: str, verbose: bool) -> str:
             n = _isa_check.check(asm)
             if verbose:
                 print(f"ISA check: all {n} clip_gemm_kernel instantiations match the counted waits")
-        except _isa_check.IsaMismatch as e:
+        except (_isa_check.IsaMismatch, IndexError, KeyError, ValueError) as e:  # (a newer hipcc may also break the checker's parsing)
             import warnings
 
             warnings.warn(f"libtamf_hip: {e}\nrebuilding with -DTAMF_CLIP_SAFE_WAIT (counted waits -> vmcnt(0))")
@@ -89,7 +113,11 @@ def _build_locked(hipcc: str, verbose: bool) -> str:
                 os.remove(os.path.join(wd, f))
             out, _ = _compile(hipcc, wd, ["-DTAMF_CLIP_SAFE_WAIT"])
             safe = True
+        digest = source_digest()  # (of the sources as they are now: an edit during the compile makes the stamp differ next time)
         os.replace(out, LIB_PATH)
+        with open(STAMP_PATH + ".tmp", "w") as f:
+            f.write(digest + "\n")
+        os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
     if verbose:
         print("built", LIB_PATH, "(safe waits)" if safe else "")
     return LIB_PATH
@@ -125,7 +153,7 @@ def load_from(path: str) -> ctypes.CDLL:
 
 
 EXPORTS = [
-    "tamf_ctx_create", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
-    "tamf_set_schedule", "tamf_set_cond", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
-    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox", "tamf_bench_gemm", "tamf_bench_attention", "tamf_bench_mfma_rate", "tamf_set_gemm_tuning",
+    "tamf_ctx_create", "tamf_ctx_resize", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
+    "tamf_set_schedule", "tamf_set_cond", "tamf_set_cond_ragged", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
+    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_refine_profile", "tamf_test_gemm", "tamf_test_gemm_ln", "tamf_test_attention", "tamf_test_philox", "tamf_test_set_guard_bytes", "tamf_test_check_guards", "tamf_test_poke", "tamf_bench_gemm", "tamf_bench_attention", "tamf_bench_mfma_rate", "tamf_set_gemm_tuning",
 ]

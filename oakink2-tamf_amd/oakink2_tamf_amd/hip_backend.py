@@ -59,6 +59,12 @@ def lib() -> ctypes.CDLL:
         L.tamf_finalize_weights.argtypes = [c_void_p, c_int32, c_void_p]
         L.tamf_set_schedule.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
         L.tamf_set_cond.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        if hasattr(L, "tamf_set_cond_ragged"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
+            L.tamf_ctx_resize.argtypes = [c_void_p, c_int32, c_int32]
+            L.tamf_set_cond_ragged.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+            L.tamf_test_set_guard_bytes.argtypes = [c_int64]
+            L.tamf_test_check_guards.argtypes = [c_void_p, POINTER(c_int32)]
+            L.tamf_test_poke.argtypes = [c_void_p, c_int32, c_int64, c_int32]
         L.tamf_denoise.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
@@ -68,6 +74,8 @@ def lib() -> ctypes.CDLL:
         L.tamf_step_kernel_count.argtypes = [c_void_p]
         L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
         L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+        if hasattr(L, "tamf_refine_profile"):
+            L.tamf_refine_profile.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
         L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
         L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
@@ -76,6 +84,11 @@ def lib() -> ctypes.CDLL:
             L.tamf_bench_mfma_rate.argtypes = [c_int32, c_int32, POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]
         _bound = True
     return L
+
+
+def set_guard_bytes(n: int) -> None:
+    """Test hook: contexts created from now on pad every device allocation with n guard bytes at both ends (0 = off)."""
+    _check(lib().tamf_test_set_guard_bytes(int(n)), None)
 
 
 def hand_side_code(hs) -> int:
@@ -196,7 +209,10 @@ class TamfContext:
 
     # -- conditioning -------------------------------------------------------------------------
     def set_cond(self, text_embedding: Optional[torch.Tensor], hand_side: Sequence, shape: torch.Tensor,
-                 obj_embedding: torch.Tensor, obj_traj: torch.Tensor):
+                 obj_embedding: torch.Tensor, obj_traj: torch.Tensor, obj_num: Optional[Sequence[int]] = None):
+        """obj_num: per-clip object counts (each in [1, nobj]) - the object means then run over each clip's own objects, as when
+        the reference's launchers call the model one clip at a time; None: over all nobj rows of the (zero-padded) batch, which is
+        what the reference's forward computes on the batch it is handed."""
         side = [hand_side_code(hs) for hs in hand_side]
         B, nobj, T, _ = obj_traj.shape
         dev = self.device
@@ -205,10 +221,16 @@ class TamfContext:
         assert sh.shape[0] == B and sh.shape[1] == T and oe.shape[0] == B and oe.shape[1] == nobj
         side_np = np.asarray(side, dtype=np.uint8)
         assert side_np.shape[0] == B
+        num_np = None
+        if obj_num is not None:
+            num_np = np.ascontiguousarray(torch.as_tensor(obj_num).cpu().numpy() if isinstance(obj_num, torch.Tensor) else obj_num, dtype=np.int32)
+            if num_np.shape != (B,):
+                raise ValueError(f"obj_num must hold one count per clip: shape {num_np.shape} for B = {B}")
         with torch.cuda.device(dev):
-            _check(lib().tamf_set_cond(self._h, B, T, nobj, c_void_p(te.data_ptr() if te is not None else 0),
-                                       side_np.ctypes.data_as(c_void_p), c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()),
-                                       c_void_p(ot.data_ptr()), c_void_p(_stream_ptr(dev))), self._h)
+            _check(lib().tamf_set_cond_ragged(self._h, B, T, nobj, num_np.ctypes.data_as(c_void_p) if num_np is not None else c_void_p(0),
+                                              c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),
+                                              c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()), c_void_p(ot.data_ptr()),
+                                              c_void_p(_stream_ptr(dev))), self._h)
         self._keep = [te, sh, oe, ot]
         self.B, self.T = int(B), int(T)
 
@@ -284,6 +306,22 @@ class TamfContext:
                    self._h)
         return int(v.value)
 
+    def resize(self, max_batch: int, max_frames: int) -> None:
+        """Re-dimension the workspaces for (max_batch, max_frames); the uploaded weights and the schedule stay.  Conditioning must be
+        set again."""
+        with torch.cuda.device(self.device):
+            _check(lib().tamf_ctx_resize(self._h, int(max_batch), int(max_frames)), self._h)
+        self.max_batch, self.max_frames = int(max_batch), int(max_frames)
+        self.B = self.T = 0
+        self._keep = []
+
+    def check_guards(self) -> int:
+        """Test hook: verify the guard bands around every device allocation of this context (set_guard_bytes() before it was
+        created).  Raises TamfError naming the allocations a kernel wrote outside of; returns the number of guarded allocations."""
+        n = c_int32(0)
+        _check(lib().tamf_test_check_guards(self._h, ctypes.byref(n)), self._h)
+        return int(n.value)
+
     def refine(self, sample_pose_repr: torch.Tensor, h2o_dist: torch.Tensor) -> torch.Tensor:
         dev = self.device
         xin, h2o = _dev_f32(sample_pose_repr, dev), _dev_f32(h2o_dist, dev)
@@ -321,6 +359,21 @@ class TamfContext:
             nm = names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
             out.append((nm, float(ms[i]), float(fl[i])))
         return out
+
+
+    def refine_profile(self, sample_pose_repr: torch.Tensor, h2o_dist: torch.Tensor, max_n: int = 256):
+        """[(name, ms, algorithmic_flops)] of one refine() call of an R context, HIP events on the launch stream."""
+        dev = self.device
+        xin, h2o = _dev_f32(sample_pose_repr, dev), _dev_f32(h2o_dist, dev)
+        assert tuple(xin.shape) == (self.B, self.T, self.input_dim) and tuple(h2o.shape) == (self.B, self.T, self.h2o_dim)
+        out = torch.empty_like(xin)
+        ms, fl, names = (c_float * max_n)(), (c_double * max_n)(), ctypes.create_string_buffer(max_n * 48)
+        with torch.cuda.device(dev):
+            n = lib().tamf_refine_profile(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()), max_n,
+                                          ms, fl, names, c_void_p(_stream_ptr(dev)))
+        if n < 0:
+            _check(n, self._h)
+        return [(names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode(), float(ms[i]), float(fl[i])) for i in range(n)]
 
 
 # ---- kernel-level test hooks ---------------------------------------------------------------------

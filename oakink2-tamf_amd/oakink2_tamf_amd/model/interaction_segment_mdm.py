@@ -81,9 +81,13 @@ class _HipDenoiserBase(nn.Module):
     supports_fused_loop = False
 
     def _init_hip(self, arch: Dict[str, int], precision: str, max_batch: Optional[int], max_frames: Optional[int],
-                  range_check: str = "fallback"):
+                  range_check: str = "fallback", per_clip_object_mean: bool = False):
         if range_check not in ("fallback", "raise", "off"):
             raise ValueError(f"range_check must be 'fallback', 'raise' or 'off', got {range_check!r}")
+        # False: the object means run over all rows of the (zero-padded) batch - the reference's forward on the batch it is given.
+        # True: over each clip's own batch["obj_num"] objects - what the reference's launchers get by calling the model one clip at a
+        # time (launch/sample.py:206, launch/sample_refine.py:228); the batched launchers of this package set it.
+        self.per_clip_object_mean = bool(per_clip_object_mean)
         self._arch = dict(arch)
         self.precision = precision          # what the caller asked for
         self.active_precision = precision   # what the library context runs ("f32" after a range fallback)
@@ -118,8 +122,11 @@ class _HipDenoiserBase(nn.Module):
         from ..hip_backend import TamfContext, require_gpu
 
         dev = require_gpu(self._device())
-        need_new = (self._ctx is None or self._ctx_dirty or B > self._ctx.max_batch or T > self._ctx.max_frames
-                    or self._ctx.device != dev)
+        need_new = self._ctx is None or self._ctx_dirty or self._ctx.device != dev
+        if not need_new and self._ctx.precision == self.active_precision and (B > self._ctx.max_batch or T > self._ctx.max_frames):
+            # a larger batch / longer clips than the workspaces hold: re-dimension them, the uploaded weights stay (tamf_ctx_resize)
+            self._ctx.resize(max(B, self._ctx.max_batch), max(T, self._ctx.max_frames))
+            self._cond_key = None
         if need_new or self._ctx.precision != self.active_precision:
             from ..hip_backend import TamfRangeError
 
@@ -174,9 +181,15 @@ class _HipDenoiserBase(nn.Module):
         address / shape / version, and the keyed OBJECTS are kept alive next to the key - a freed batch dict or tensor
         can therefore never be mistaken for a new one that the allocator placed at the same address."""
         tensors = (text_embedding, batch["shape"], batch["obj_embedding"], batch["obj_traj"])
-        key = (id(batch), tuple(batch["hand_side"])) + tuple(self._tensor_key(t) for t in tensors)
+        obj_num = None
+        if self.per_clip_object_mean:
+            if "obj_num" not in batch:
+                raise KeyError("per_clip_object_mean=True needs batch['obj_num'] (the collate carries it, dataset/collate.py)")
+            n = batch["obj_num"]
+            obj_num = tuple(int(v) for v in (n.tolist() if hasattr(n, "tolist") else n))
+        key = (id(batch), tuple(batch["hand_side"]), obj_num) + tuple(self._tensor_key(t) for t in tensors)
         if key != self._cond_key:
-            ctx.set_cond(text_embedding, batch["hand_side"], batch["shape"], batch["obj_embedding"], batch["obj_traj"])
+            ctx.set_cond(text_embedding, batch["hand_side"], batch["shape"], batch["obj_embedding"], batch["obj_traj"], obj_num=obj_num)
             self._cond_key = key
             self._cond_refs = (batch,) + tensors
 
@@ -193,7 +206,8 @@ class InterationSegmentMDM(_HipDenoiserBase):
     def __init__(self, input_dim=99, obj_input_dim=9, hand_shape_dim=10, obj_embed_dim=768, latent_dim=256,
                  ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu", clip_dim=512,
                  clip_version="ViT-B/32", precision: Optional[str] = None, load_clip: bool = False,
-                 max_batch: Optional[int] = None, max_frames: Optional[int] = None, range_check: str = "fallback", **kargs):
+                 max_batch: Optional[int] = None, max_frames: Optional[int] = None, range_check: str = "fallback",
+                 per_clip_object_mean: bool = False, **kargs):
         super().__init__()
         if activation != "gelu":
             raise NotImplementedError("the HIP FFN kernel fuses the exact erf-GELU (activation='gelu') only")
@@ -227,7 +241,7 @@ class InterationSegmentMDM(_HipDenoiserBase):
         self._init_hip(dict(input_dim=input_dim, obj_input_dim=obj_input_dim, hand_shape_dim=hand_shape_dim,
                             obj_embed_dim=obj_embed_dim, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers,
                             num_heads=num_heads, clip_dim=clip_dim), precision or _default_precision(), max_batch, max_frames,
-                       range_check)
+                       range_check, per_clip_object_mean)
 
     def parameters_wo_clip(self):
         return [p for name, p in self.named_parameters() if not name.startswith("clip_model.")]

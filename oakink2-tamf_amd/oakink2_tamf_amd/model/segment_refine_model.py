@@ -27,7 +27,7 @@ class SegmentRefineModel(_HipDenoiserBase):
     def __init__(self, mano_path=None, input_dim=99, obj_input_dim=9, hand_shape_dim=10, obj_embed_dim=768,
                  latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu", use_pc=False,
                  h2o_dim=778, precision=None, max_batch=None, max_frames=None, mano_layer_rh=None,
-                 mano_layer_lh=None, range_check: str = "fallback"):
+                 mano_layer_lh=None, range_check: str = "fallback", per_clip_object_mean: bool = False):
         super().__init__()
         if activation != "gelu":
             raise NotImplementedError("the HIP FFN kernel fuses the exact erf-GELU (activation='gelu') only")
@@ -55,7 +55,7 @@ class SegmentRefineModel(_HipDenoiserBase):
         self._init_hip(dict(input_dim=input_dim, obj_input_dim=obj_input_dim, hand_shape_dim=hand_shape_dim,
                             obj_embed_dim=obj_embed_dim, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers,
                             num_heads=num_heads, h2o_dim=h2o_dim), precision or _default_precision(), max_batch, max_frames,
-                       range_check)
+                       range_check, per_clip_object_mean)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         # checkpoints of the reference also carry the manotorch buffers (mano_layer_rh.*, mano_layer_lh.*)

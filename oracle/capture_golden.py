@@ -392,6 +392,94 @@ def capture_collate():
     print("collate:", {k: (tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else type(v).__name__ for k, v in out.items()})
 
 
+def _install_toolkit_stubs():
+    """oakink2_toolkit (dataset walker + constants) and manotorch are absent; dataset/interaction_segment.py imports both at
+    module level.  With a cache dict its constructor only instantiates OakInk2__Dataset and, for enable_obj_model, asks it
+    for the object meshes: the stub serves the synthetic meshes of oracle.fixtures."""
+    from types import SimpleNamespace
+
+    from . import fixtures
+
+    tk = types.ModuleType("oakink2_toolkit")
+    tk.dataset = types.ModuleType("oakink2_toolkit.dataset")
+    tk.meta = types.ModuleType("oakink2_toolkit.meta")
+
+    class OakInk2__Dataset:
+        def __init__(self, dataset_prefix=None, return_instantiated=True):
+            self.dataset_prefix = dataset_prefix
+
+        def load_affordance(self, obj_id):
+            v, f = fixtures.synthetic_object_mesh(obj_id)
+            return SimpleNamespace(obj_mesh=SimpleNamespace(vertices=v, faces=f))
+
+    tk.dataset.OakInk2__Dataset = OakInk2__Dataset
+    tk.meta.FPS_MOCAP, tk.meta.HAND_SIDE, tk.meta.HAND_SIDE_MAP = 120.0, ["rh", "lh"], {"rh": "right", "lh": "left"}
+    for name, mod in (("oakink2_toolkit", tk), ("oakink2_toolkit.dataset", tk.dataset), ("oakink2_toolkit.meta", tk.meta)):
+        sys.modules[name] = mod
+    if "manotorch" not in sys.modules:
+        sys.modules["manotorch"] = types.ModuleType("manotorch")
+
+
+def _items_to_arrays(prefix, items, arrays):
+    """item dicts -> npz entries: arrays as they are (dtype kept), everything else as one JSON document per item"""
+    import json
+
+    for i, it in enumerate(items):
+        meta = {}
+        for k, v in it.items():
+            if isinstance(v, np.ndarray):
+                arrays[f"{prefix}/{i}/{k}"] = v
+            elif isinstance(v, list) and v and isinstance(v[0], np.ndarray):
+                for j, a in enumerate(v):
+                    arrays[f"{prefix}/{i}/{k}/{j}"] = a
+                meta[k] = {"__arrays__": len(v)}
+            else:
+                meta[k] = v
+        arrays[f"{prefix}/{i}/__meta__"] = np.array(json.dumps(meta))
+        arrays[f"{prefix}/{i}/__keys__"] = np.array(list(it.keys()))
+
+
+def capture_cache_dict():
+    """Row 8(f)-3, input side: the reference's InteractionSegmentData on its cache-dict path (constructor :285-387 with the
+    toolkit stubbed, __getitem__ :389-449, reverse twins :162-265), GeneratedPoseReprSampleAdaptor (pose_repr_sample.py:18-52)
+    over a two-directory .npy tree, and the slicer (setment_slice.py:10-36) - on oracle.fixtures' synthetic segment cache."""
+    import tempfile
+
+    _install_toolkit_stubs()
+    from oakink2_tamf.dataset.interaction_segment import InteractionSegmentData
+    from oakink2_tamf.dataset.pose_repr_sample import GeneratedPoseReprSampleAdaptor
+    from oakink2_tamf.dataset.setment_slice import segment_slice_from_gap
+
+    from . import fixtures
+
+    arrays = {}
+    with tempfile.TemporaryDirectory() as root:
+        paths, cache = fixtures.write_synthetic_dataset(root)
+        ds = InteractionSegmentData(process_range_list=["ignored"], data_prefix="/nonexistent", obj_embedding_prefix=paths["emb"],
+                                    enable_obj_model=True, obj_pointcloud_prefix=paths["pc"], cache_dict=cache)
+        _items_to_arrays("fwd", [ds[i] for i in range(len(ds))], arrays)
+        ds_rev = InteractionSegmentData(process_range_list=[], data_prefix="/nonexistent", obj_embedding_prefix=paths["emb"],
+                                        cache_dict=cache, append_reverse_segment=True)
+        assert len(ds_rev) == 2 * len(ds)
+        _items_to_arrays("rev", [ds_rev[i] for i in range(len(ds), len(ds_rev))], arrays)
+        # the G stage's output tree: two directories, names out of numeric order on purpose
+        dirs = [os.path.join(root, "sample", "b_part"), os.path.join(root, "sample", "a_part")]
+        split = [[3, 0, 10], [2, 1]]
+        for d, ids in zip(dirs, split):
+            os.makedirs(d)
+            for sid in ids:
+                np.save(os.path.join(d, f"{sid:06d}.npy"), fixtures.synthetic_sample_pose_repr(os.path.basename(d), sid))
+        ds_plain = InteractionSegmentData(process_range_list=[], data_prefix="/nonexistent", obj_embedding_prefix=paths["emb"], cache_dict=cache)
+        ad = GeneratedPoseReprSampleAdaptor(ds_plain, dirs)
+        _items_to_arrays("adaptor", [ad[i] for i in range(len(ad))], arrays)
+    for n, gap, mx, mn in ((500, 12, 160, 16), (100, 12, 160, 16), (5000, 12, 160, 16), (1920, 12, 160, 16), (192, 12, 160, 16)):
+        traj = np.arange(n * 2, dtype=np.float32).reshape(n, 2)
+        clips, lens = segment_slice_from_gap(traj, gap, mx, mn)
+        arrays[f"slice/{n}/clips"], arrays[f"slice/{n}/lens"] = np.stack(clips), np.asarray(lens)
+    np.savez_compressed(os.path.join(OUT_DIR, "cache_dict_items.npz"), **arrays)
+    print("cache_dict:", len(ds), "items,", len(arrays), "arrays,", os.path.getsize(os.path.join(OUT_DIR, "cache_dict_items.npz")) >> 10, "KiB")
+
+
 def capture_siv():
     """Row 8(f)-4 (SIV): the reference's check_mesh_contains (dev_fn/external/libmesh/inside_mesh.py) with its Cython
     TriangleHash built from the reference source by oracle/build_ref.sh into oracle/_ref/libmesh.  The package is assembled at
@@ -477,6 +565,7 @@ def main():
     capture_vertex_normals()
     capture_contact()
     capture_collate()
+    capture_cache_dict()
     capture_siv()
 
 

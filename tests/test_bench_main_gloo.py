@@ -33,6 +33,23 @@ def test_bench_self_spawns_two_ranks_and_gathers():
     assert j["value"] > 0 and abs(j["value"] - 6 * 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
 
 
+def test_bench_world_8_as_the_scaling_run_will_launch_it():
+    """The driver's 8-GPU form, `--gpus 8` (SCALE_rNN.json), on CPU: eight self-spawned ranks, eight contiguous clip ranges, one gather
+    per loop, one JSON line whose value counts the clips of ALL ranks - the builder never holds more than one GPU, so this is the
+    closest rehearsal of the first 8-GPU contact that can run before it."""
+    r = _run(["--gpus", "8", "--config", "3", "--batch", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["world_size_seen"] == 8 and j["config"]["preset"] == 3
+    assert j["config"]["rank_clip_ranges"] == [[2 * k, 2 * k + 2] for k in range(8)] and j["config"]["global_clips"] == 16
+    ranks = j["config"]["ranks"]
+    assert [i["rank"] for i in ranks] == list(range(8)) and len({i["pid"] for i in ranks}) == 8 and all(i["finite"] for i in ranks)
+    assert abs(j["value"] - 16 * 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    assert "cpu_baseline" not in j and "other_dtypes" not in j  # N > 1: no per-point host measurement, no extra modes
+
+
 def test_a_dead_rank_ends_its_siblings():
     """spawn_ranks watches its children: rank 1 exits with 7 before the process-group set-up, rank 0 - which would sit in the
     rendezvous until its timeout - is terminated, and the launcher returns rank 1's code within seconds."""
@@ -69,7 +86,15 @@ def test_bench_presets():
     a = bench.parse_args(["--config", "5"])
     assert a.batch == 64 and a.dtype == "bf16"
     a = bench.parse_args([])
-    assert a.batch == 64 and a.frames == 196 and a.ddpm_steps == 1000 and a.gpus == 1
+    assert a.batch == 64 and a.frames == 196 and a.ddpm_steps == 1000 and a.gpus == 1 and a.steps == 3 and a.warmup == 1
+    a = bench.parse_args(["--config", "4"])  # BASELINE configs[3]: the R trunk, one forward per step
+    assert a.arch == "arch_refine" and a.batch == 64 and a.frames == 196 and a.steps == 200 and a.warmup == 20
+    a = bench.parse_args(["--config", "4", "--steps", "7", "--warmup", "2"])
+    assert (a.steps, a.warmup) == (7, 2)
+    import pytest
+
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--arch", "arch_refine"])
     assert bench.flops_per_clip_step(bench.ARCHS["arch_mdm_l"], 196) == 11127660544  # 11.128 GF per clip-step
 
 

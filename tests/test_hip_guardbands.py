@@ -1,0 +1,128 @@
+"""GPU: out-of-bounds stores, caught by guard bands around every device allocation (VERDICT r4 "next" #4).
+
+GPU AddressSanitizer is not available for gfx950 on this pool, and the sweeps of tests/test_hip_fullsize.py compare kernels with
+kernels: an out-of-bounds WRITE that lands in a neighbouring live buffer and is overwritten later passes them (the V^T overrun of
+round 4 lived through a green round).  Here every allocation of a context is padded with 4 KiB of a byte pattern at both ends
+(tamf_test_set_guard_bytes) and the margins are verified after the calls (tamf_test_check_guards).  The context is dimensioned EXACTLY
+for the shape it runs (tamf_ctx_resize keeps the weights, so a new shape costs milliseconds): a kernel that writes past the rows /
+keys / clips of its shape writes into a margin.
+
+Swept: EVERY clip length T = 1 .. 224 at B in {1, 31, 32, 64, 65}, for G (arch_mdm_l: one evaluation; a short hipGraph DDPM loop on
+every 8th length) and R (arch_refine trunk), in f16x3, f32 and bf16."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 4096
+BATCHES = (1, 31, 32, 64, 65)
+LENGTHS = range(1, 225)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def guard_mode():
+    from oakink2_tamf_amd.hip_backend import set_guard_bytes
+
+    set_guard_bytes(GUARD)
+    yield
+    set_guard_bytes(0)
+
+
+def _inputs(B, T, nobj=2):
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    return {"text": torch.randn(B, 512, generator=g).cuda(), "side": ["rh" if b % 2 == 0 else "lh" for b in range(B)],
+            "shape": torch.randn(B, T, 10, generator=g).cuda(), "emb": torch.randn(B, nobj, 768, generator=g).cuda(),
+            "traj": torch.randn(B, nobj, T, 9, generator=g).cuda(), "x": torch.randn(B, 99, 1, T, generator=g).cuda(),
+            "t": torch.randint(0, 1000, (B,), generator=g).cuda()}
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32", "bf16"])
+def test_g_every_clip_length_writes_inside_its_buffers(prec):
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfError
+
+    arch = O.ARCH_MDM_L
+    a = dict(latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    sd = O.det_state_dict(arch, tag="guard/g")
+    tab = O.make_tables(4, "cosine")
+    ctx = TamfContext(a, 1, 1, precision=prec, device="cuda:0")
+    ctx.load_state_dict(sd)
+    ctx.set_schedule(tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+    n_guarded = ctx.check_guards()
+    assert n_guarded > 100  # workspaces + every weight / table allocation
+    bad, cases = [], 0
+    for B in BATCHES:
+        for T in LENGTHS:
+            ctx.resize(B, T)
+            i = _inputs(B, T)
+            ctx.set_cond(i["text"], i["side"], i["shape"], i["emb"], i["traj"], obj_num=[1 + b % 2 for b in range(B)] if T % 2 else None)
+            out = ctx.denoise(i["x"], i["t"])
+            if T % 8 == 4:
+                out = ctx.sample_loop(noise=None, seed=T, clip_id_base=7)
+            try:
+                ctx.check_guards()
+            except TamfError as e:
+                bad.append((B, T, str(e)[:600]))
+                ctx.resize(B, T)  # fresh margins for the next shape
+            if not bool(torch.isfinite(out).all()):
+                bad.append((B, T, "non-finite output"))
+            cases += 1
+    ctx.close()
+    assert not bad, (prec, len(bad), bad[:5])
+    assert cases == len(BATCHES) * len(LENGTHS)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32", "bf16"])
+def test_r_every_clip_length_writes_inside_its_buffers(prec):
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfError
+
+    arch = O.ARCH_REFINE
+    a = dict(latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    sd = O.det_state_dict(arch, tag="guard/r")
+    ctx = TamfContext(a, 1, 1, precision=prec, device="cuda:0", kind="R")
+    ctx.load_state_dict(sd)
+    bad = []
+    for B in BATCHES:
+        for T in LENGTHS:
+            ctx.resize(B, T)
+            i = _inputs(B, T, nobj=3)
+            ctx.set_cond(None, i["side"], i["shape"], i["emb"], i["traj"])
+            g = torch.Generator().manual_seed(T)
+            out = ctx.refine(torch.randn(B, T, 99, generator=g).cuda(), (torch.randn(B, T, 778, generator=g) * 0.05).cuda())
+            try:
+                ctx.check_guards()
+            except TamfError as e:
+                bad.append((B, T, str(e)[:600]))
+                ctx.resize(B, T)
+            if not bool(torch.isfinite(out).all()):
+                bad.append((B, T, "non-finite output"))
+    ctx.close()
+    assert not bad, (prec, len(bad), bad[:5])
+
+
+def test_the_guard_bands_do_catch_an_overrun():
+    """the checker itself: bytes written right behind a workspace and right below a weight are reported with allocation and offset"""
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfError, lib
+
+    arch = O.ARCH_TINY
+    a = dict(latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    ctx = TamfContext(a, 2, 16, precision="f32", device="cuda:0")
+    ctx.load_state_dict(O.det_state_dict(arch, tag="guard/t"))
+    assert ctx.check_guards() > 20
+    i = _inputs(2, 16)
+    ctx.set_cond(i["text"], i["side"], i["shape"], i["emb"], i["traj"])
+    ctx.denoise(i["x"], i["t"])
+    ctx.check_guards()
+    xs_bytes = 2 * 16 * 128 * 4  # allocation #0 = the sampler state `xs`: [B * T][128] fp32
+    assert lib().tamf_test_poke(ctx._h, 0, xs_bytes, 4) == 0  # 4 bytes right behind it
+    with pytest.raises(TamfError, match=r"allocation #0 .*xs.* BEYOND its end \(offsets \+0 \.\. \+3\)"):
+        ctx.check_guards()
+    ctx.resize(2, 16)  # new workspaces, new margins; the weights' margins are untouched
+    ctx.check_guards()
+    assert lib().tamf_test_poke(ctx._h, 3, -8, 8) == 0  # 8 bytes right below allocation #3 (a weight, now that the workspaces are at the end)
+    with pytest.raises(TamfError, match=r"allocation #3 .* BELOW its start \(offsets -8 \.\. -1\)"):
+        ctx.check_guards()
+    ctx.close()

@@ -147,10 +147,22 @@ def test_cli_config_surface(tmp_path):
     assert cfg["ckpt_path"].endswith(os.path.join("common", "sample", "main"))
     assert cfg["debug"]["sample_save_offset"] == "test/arch_mdm_l__0399"
     known, dotted = S.parse_args(["--synthetic", "3,16"])
-    cond = S.load_conditioning(S.build_config(known, dotted), known)
-    assert cond["obj_traj"].shape == (3, 2, 16, 9) and cond["shape"].shape == (3, 16, 10)
-    with pytest.raises(SystemExit):
-        S.load_conditioning(S.build_config(*S.parse_args([])), S.parse_args([])[0])
+    clips = S.load_clips(S.build_config(known, dotted), known)
+    assert clips.cond["obj_traj"].shape == (3, 2, 16, 9) and clips.cond["shape"].shape == (3, 16, 10) and (clips.n, clips.frames) == (3, 16)
+    monkey_cwd = os.getcwd()
+    os.chdir(tmp_path)  # no segment cache at the reference's default place under the working directory
+    try:
+        with pytest.raises(SystemExit, match="segment cache"):
+            S.load_clips(S.build_config(*S.parse_args([])), S.parse_args([])[0])
+    finally:
+        os.chdir(monkey_cwd)
+    # a dotted flag the launcher does not register is an error, as with the reference's config_reg (not silently dropped)
+    for bad in (["--runtime.devce_id", "0"], ["--data.cache_dict", "x.pkl"], ["--model.latent_dim", "many"], ["--data.cond_npz"]):
+        with pytest.raises(SystemExit):
+            S.parse_args(bad)
+    known, dotted = S.parse_args(["--runtime.batch_size=8", "--data.process_range", "?(file:./asset/split/test.txt):scene_a"])
+    assert dotted["runtime.batch_size"] == 8 and dotted["data.process_range"] == ["scene_a"]  # (the split file does not exist: no entries)
+    assert S.split_outside_macros("a:?(file:x:y.txt),b") == ["a", "?(file:x:y.txt)", "b"]
 
 
 def test_refine_oracle_matches_reference():
@@ -186,7 +198,7 @@ def test_file_macro_and_process_range(tmp_path):
     known, dotted = S.parse_args(["--data.cond_npz", str(npz), "--data.process_range", f"scene_c,?(file:{lst})"])
     cfg = S.build_config(known, dotted)
     assert cfg["data"]["process_range"] == ["scene_c", "scene_b", "scene_a"]
-    cond = S.load_conditioning(cfg, known)
+    cond = S.load_clips(cfg, known).cond
     assert cond["shape"].shape[0] == 3 and list(cond["hand_side"]) == ["rh", "rh", "rh"]  # clips 0, 2, 4 in file order
     # defaults: one worker per visible device, decided in main() (not the reference's 8 workers on devices 0-3)
     assert cfg["runtime"]["num_worker"] is None and cfg["runtime"]["device_id"] is None
