@@ -524,7 +524,7 @@ def main_refine(args, dev, ptrace):
         r = run_mode(dt, max(20, args.steps // 4), 5)
         ms = r["elapsed"] / max(20, args.steps // 4) * 1e3
         other[dt] = {"value": B * T / ms * 1e3, "unit": "frames/s", "ms_per_batch": ms, "finite": r["finite"],
-                     "whole_path_tflops": r["forward_gflop"] / ms / 1e3, "whole_path_frac_of_peak": r["forward_gflop"] / ms / 1e3 / PEAK_TFLOPS[dt],
+                     "whole_path_tflops": r["forward_gflop"] / ms, "whole_path_frac_of_peak": r["forward_gflop"] / ms / PEAK_TFLOPS[dt],  # (GFLOP per ms = TFLOP/s)
                      "dominant_kernel": r["profile"][0]["kernel"], "dominant_kernel_frac": r["profile"][0]["tflops"] / PEAK_TFLOPS[dt]}
         finite_by[dt] = r["finite"]
         if r["err"] is not None:

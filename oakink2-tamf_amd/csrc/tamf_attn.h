@@ -290,12 +290,20 @@ TAMF_DEV int attn_xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+constexpr int attn_res_maxw(int nkb) { return nkb <= 4 ? 8 : 16; }  // waves per workgroup of attn_res_kernel<.., nkb> (AttnRes::MAXW)
 template <class Op, int HD, int NKB_>
 struct AttnRes {
   typedef AttnCfg<Op, HD> C;
   typedef AttnBlock<Op, HD> BLK;
   static constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16;
   static constexpr int NKB = NKB_, NKT = 2 * NKB;        // key blocks / key tiles held in registers (S <= 32 NKB)
+  // waves per workgroup the kernel is built for: a clip of up to NKT key tiles has at most NKT query tiles (one wave each); the
+  // short-clip form (NKB = 4: S <= 128, every clip of up to 123 frames) therefore never runs more than 8 waves, i.e. 2 per SIMD and
+  // 256 registers per lane - with __launch_bounds__(1024) it was held to 128 and spilled 880 - 1 048 bytes per lane (round 4 verdict)
+  static constexpr int MAXW = attn_res_maxw(NKB_);
+  // shortest sequence this instantiation is launched for (launch_attn takes the smallest NKB that fits: 4 up to 128 keys, 6 up to
+  // 192, 7 up to 224); key tiles entirely below it are never masked
+  static constexpr int S_MIN = NKB_ <= 4 ? 1 : NKB_ <= 6 ? 129 : 193;
   static constexpr int LDS_MAX = 160 * 1024;
   static constexpr bool TWO = Op::SPLIT || Op::PREC == 0;  // two 16-byte V^T fragments per lane and feature tile (hi | lo, or f32's two key groups)
 
@@ -307,7 +315,7 @@ struct AttnRes {
   }
   static bool fits(int S, int Sp) {
     const int nkb = (S + 31) / 32;
-    if (nkb > NKB || Sp > NKT * 16 || (k_bytes(Sp) % 1024) != 0) return false;
+    if (nkb > NKB || S < S_MIN || Sp > NKT * 16 || (k_bytes(Sp) % 1024) != 0) return false;
     const int n1 = nv1(Sp, nkb);
     return n1 >= 1 && (nkb - n1) * C::V_BYTES <= k_bytes(Sp);
   }
@@ -472,7 +480,7 @@ struct AttnRes {
 };
 
 template <class Op, int HD, int NKB_>
-__global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
+__global__ __launch_bounds__(attn_res_maxw(NKB_) * 64) void attn_res_kernel(const AttnArgs<Op> aa) {
   typedef AttnCfg<Op, HD> C;
   typedef AttnRes<Op, HD, NKB_> R;
   constexpr int EB = Op::EB, KG = C::KG, NT16 = HD / 16, NKB = R::NKB, NKT = R::NKT;
@@ -559,10 +567,11 @@ __global__ __launch_bounds__(1024) void attn_res_kernel(const AttnArgs<Op> aa) {
   // ---- exact softmax over the keys (per query = per lane column; the 4 lane groups hold disjoint keys)
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
-    if (kt * 16 + 15 >= S) {  // (wave-uniform: only the last tiles can hold keys >= S)
+    if (kt * 16 + 15 >= R::S_MIN) {  // (compile time: only these tiles can hold keys >= S for the clip lengths this instantiation serves)
+      // branch-free: a (wave-uniform) branch around the rewrite made every st[] a phi of two versions, and the short-clip form - where
+      // all eight tiles can be masked - ended up with 1 000 register moves and 352 - 1 048 bytes of spills per lane (round 4 verdict #8)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (kt * 16 + 4 * g + r >= S) st[kt][r] = -1e30f;
+      for (int r = 0; r < 4; ++r) st[kt][r] = (kt * 16 + 4 * g + r >= S) ? -1e30f : st[kt][r];
     }
   float m = -1e30f;
 #pragma unroll

@@ -436,6 +436,105 @@ TAMF_DEV float ln_row_sum512(const float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deferred LayerNorm (round 5; the 16-bit arithmetic modes).
+//
+// The reference's encoder layer is post-LN: x = LayerNorm(u), u = x_prev + sublayer(x_prev) (interaction_segment_mdm.py:63-70, torch
+// nn.TransformerEncoderLayer, eps 1e-5).  A LayerNorm needs whole rows, and no tiling of whole rows fills 256 CUs (rounds 2 - 4: the
+// 64 x d LayerNorm-fused tile ran at 7 - 20 % of peak, the separate LayerNorm kernels moved 109 MB each).  So the normalised value is
+// never materialised: the residual stream holds the UN-normalised sums u (fp32 + operand), the GEMM that produces a row block also
+// leaves partial statistics of it, and every consumer applies the normalisation itself -
+//   a GEMM over LN(u):     LN(u) . W^T = rstd[m] (u . (gamma o W)^T - mean[m] c1[n]) + c2[n],   c1 = (gamma o W) 1,  c2 = W beta + b
+//                          (gamma folded into the weights, c1 / c2 computed at tamf_finalize_weights; Epi*::ln);
+//   the residual add:      u_next[m][n] = ((u[m][n] - mean[m]) rstd[m] gamma[n] + beta[n]) + (acc + bias)           (EpiResid).
+// Statistics: the producer's epilogue writes, per row and per block of 32 columns, (S_b, Q_b) = (sum, sum of squares about the
+// block's own mean); a consumer stages (mean, rstd) of its tile's rows in LDS before its K loop (ln_stage).  Both are fixed trees -
+// the same for the LDS-walking 128 x 128 tiles and for the register epilogue of the clip tiles - so a clip's bits do not depend
+// on the batch it is in or on the kernel selection (the batch-invariance tests).
+// ---------------------------------------------------------------------------------------------
+struct LnStats {
+  const float2* part;  // [rows][NB] (S_b, Q_b); null: no LayerNorm in front of this row block (mean 0, rstd 1)
+  int NB;              // d / 32: 4, 8 or 16
+  float inv_d, eps;
+};
+
+// (S, Q) of 32 consecutive columns of one row, held as 8 consecutive values in each of 4 lanes: the lanes of a quad (LDS-walking
+// epilogues: GROUPS = false) or the 4 lane groups l, l ^ 16, l ^ 32, l ^ 48 (register epilogue of the clip tiles: GROUPS = true).
+// Every one of the 4 lanes gets the result.  One tree: lane sums ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)), then
+// (l0 + l1) + (l2 + l3); no fused multiply-adds (the same bits whatever code surrounds the call).
+template <bool GROUPS>
+TAMF_DEV float ln_sum4(float p) {
+  if constexpr (GROUPS) {
+    return groups_reduce<RedSum>(p);
+  } else {
+    p = p + dpp_mov<DPP_XOR1>(p);
+    return p + dpp_mov<DPP_XOR2>(p);
+  }
+}
+template <bool GROUPS>
+TAMF_DEV float2 ln_block_partial(const float (&v)[8]) {
+#pragma clang fp contract(off)
+  const float p = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  const float S = ln_sum4<GROUPS>(p);
+  const float mb = S * 0.03125f;
+  float q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float dlt = v[j] - mb;
+    q[j] = dlt * dlt;
+  }
+  const float qq = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  return make_float2(S, ln_sum4<GROUPS>(qq));
+}
+
+// (mean, rstd) of rows [r0, r0 + rows) into out[0 .. rows) (LDS), by NT threads, 4 lanes (a quad) per row: lane q of the quad takes the
+// blocks q NB/4 .. (q + 1) NB/4 - 1 in order, the quad combines as (q0 + q1) + (q2 + q3).  mean = S / d;
+// M2 = sum_b (Q_b + 32 (S_b / 32 - mean)^2); rstd = 1 / sqrt(M2 / d + eps).  Rows past row_limit are clamped (their value is never used).
+template <int NT>
+TAMF_DEV void ln_stage(const LnStats& s, int r0, int rows, int row_limit, float2* out, int tid) {
+#pragma clang fp contract(off)
+  static_assert(NT % 64 == 0, "whole waves");
+  const int q = tid & 3;
+  for (int r = tid >> 2; r < rows; r += NT / 4) {  // (a quad shares r: its four lanes enter and leave together, the DPP steps see all of them)
+    float2 res = make_float2(0.f, 1.f);
+    if (s.part) {
+      int gr = r0 + r;
+      gr = gr < row_limit ? gr : row_limit - 1;
+      const int nbq = s.NB >> 2;
+      const float2* p = s.part + (long)gr * s.NB + q * nbq;
+      float sb[4], qb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sb[i] = qb[i] = 0.f;
+      if (nbq == 4) {
+        const float4 x = *(const float4*)p, y = *(const float4*)(p + 2);
+        sb[0] = x.x; qb[0] = x.y; sb[1] = x.z; qb[1] = x.w; sb[2] = y.x; qb[2] = y.y; sb[3] = y.z; qb[3] = y.w;
+      } else if (nbq == 2) {
+        const float4 x = *(const float4*)p;
+        sb[0] = x.x; qb[0] = x.y; sb[1] = x.z; qb[1] = x.w;
+      } else {
+        const float2 x = *p;
+        sb[0] = x.x; qb[0] = x.y;
+      }
+      float S = sb[0];
+#pragma unroll
+      for (int i = 1; i < 4; ++i)
+        if (i < nbq) S = S + sb[i];
+      S = ln_sum4<false>(S);
+      const float mean = S * s.inv_d;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nbq) {
+          const float dm = sb[i] * 0.03125f - mean;
+          m2 = m2 + (qb[i] + 32.0f * (dm * dm));
+        }
+      m2 = ln_sum4<false>(m2);
+      res = make_float2(mean, 1.0f / sqrtf(m2 * s.inv_d + s.eps));
+    }
+    if (q == 0 && r < rows) out[r] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller (restated in oracle/mdm_oracle.py:philox_normal)
 // ---------------------------------------------------------------------------------------------
 TAMF_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

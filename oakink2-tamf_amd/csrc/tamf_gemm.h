@@ -43,6 +43,8 @@ struct GemmSmem {
   static constexpr int STAGE = (BM + BN) * GEMM_BKB;
   static constexpr int CBYTES = BM * LDC * 4;
   static constexpr int BYTES = (2 * STAGE > CBYTES) ? 2 * STAGE : CBYTES;
+  // + (mean, rstd) of the tile's rows for the epilogues that normalise (deferred LayerNorm, tamf_device.h): staged ahead of the K loop
+  static constexpr int STATS_OFF = BYTES, TOTAL = BYTES + BM * 8;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -79,13 +81,24 @@ TAMF_DEV void settle(const float (&v)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) asm volatile("" ::"v"(v[j]));
 }
+// Deferred LayerNorm in front of a GEMM (tamf_device.h): out = rstd (acc ws - mean c1[n]) + c2[n] = fma(acc, ra, fma(rb, c1[n], c2[n])) with the row
+// terms ra = rstd ws, rb = -(rstd mean).  Explicit roundings: every kernel shape produces the same bits.  With (mean, rstd) = (0, 1)
+// - no LayerNorm in front - it is fma(acc, ws, c2[n]) bit for bit.
+struct RowAff {
+  float ra, rb;
+};
+TAMF_DEV RowAff row_aff(float2 st, float ws) { return RowAff{__fmul_rn(st.y, ws), -__fmul_rn(st.y, st.x)}; }
+TAMF_DEV float aff(float acc, const RowAff& a, float c1, float c2) { return fmaf(acc, a.ra, fmaf(a.rb, c1, c2)); }
+
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
   gst16f(p, v[0], v[1], v[2], v[3]);
   gst16f(p + 4, v[4], v[5], v[6], v[7]);
 }
 
 // out = act(C + bias[n] + rowadd[m][n]) stored as an operand (FFN1+GELU, input_merge.0+SiLU, hoisted GEMMs)
-template <class OutOp>
+// LN = true: the A operand holds UN-normalised rows u and the LayerNorm in front of this GEMM is applied here (deferred LayerNorm):
+// bias = c2, c1 = column sums of the gamma-folded weight, ln = partial statistics of the rows (staged by the kernel: `rs`).
+template <class OutOp, bool LN = false>
 struct EpiBiasAct {
   const float* bias;    // [N] or null
   const float* rowadd;  // [M][ld_rowadd] or null
@@ -94,16 +107,24 @@ struct EpiBiasAct {
   int ldo;
   int act;
   EpiCtl ctl;
+  const float* c1 = nullptr;  // [N] (LN)
+  LnStats ln{};
+  static constexpr bool ROWSTATS = LN;
   // Column constants of a thread (its 8 columns are the same for all its rows): loaded once per tile, ahead of the row
   // loops - a global load inside the row loop serialises the loop on L2 latency, and a load issued after stores waits for
   // them (vmcnt is in order), which is why the slab-wise epilogue of tamf_gemm_clip.h fetches these before its first slab
   struct Cols {
     float bi[8];
+    float ci[LN ? 8 : 1];
     // a (free) register use that makes the compiler wait for the loads HERE, once: left to the first use inside a row loop,
     // its s_waitcnt vmcnt(0) is repeated every iteration and then waits for the previous iteration's stores
     TAMF_DEV void settle() const {
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(bi[j]));
+      if constexpr (LN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ci[j]));
+      }
     }
   };
   template <int BN, int NT>
@@ -113,19 +134,29 @@ struct EpiBiasAct {
 #pragma unroll
     for (int j = 0; j < 8; ++j) c.bi[j] = 0.f;
     if (bias) g_load8(bias + n0 + (tid % VPR) * 8, c.bi);
+    if constexpr (LN) g_load8(c1 + n0 + (tid % VPR) * 8, c.ci);
     return c;
   }
   template <int BM, int BN, int NT>
-  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    run_c<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, cols<BN, NT>(n0, tid));
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs = nullptr) const {
+    run_c<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, cols<BN, NT>(n0, tid), rs);
   }
   template <int BM, int BN, int NT>
-  TAMF_DEV void run_c(const float* Ct, int LDC, int m0, int n0, int M, int tid, const Cols& cc) const {
+  TAMF_DEV void run_c(const float* Ct, int LDC, int m0, int n0, int M, int tid, const Cols& cc, const float2* rs = nullptr) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;
     float am = 0.f;
-    if (rowadd) {
+    if constexpr (LN) {
+      cc.settle();
+      for (int row = tid / VPR; row < BM; row += RSTEP) {
+        const int gr = m0 + row;
+        if (gr >= M) break;
+        float v[8];
+        ct_load8(Ct, LDC, row, col, v);
+        finish_ln<8>(act, gr, gn, v, cc.bi, cc.ci, rs[row], am);
+      }
+    } else if (rowadd) {
       // the row terms of all of this thread's rows are requested (and waited for) before the first store: a load issued behind
       // stores waits for them (vmcnt retires in order) - one store round trip per row otherwise (input_merge.0)
       constexpr int NR = BM / RSTEP;
@@ -178,6 +209,19 @@ struct EpiBiasAct {
     }
     act_store<N>(a, gr, gn, v, am);
   }
+  // the same with the deferred LayerNorm of the row (st = its (mean, rstd)): bi = c2, ci = c1
+  template <int N>
+  TAMF_DEV void finish_ln(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&ci)[N], float2 st, float& am) const {
+    const RowAff ra = row_aff(st, ctl.wscale);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = aff(v[j], ra, ci[j], bi[j]);
+    act_store<N>(a, gr, gn, v, am);
+  }
+  template <int N>
+  TAMF_DEV void lane_cols_ln(int gn, float (&bi)[N], float (&ci)[N]) const {
+    g_loadn<N>(bias + gn, bi);
+    g_loadn<N>(c1 + gn, ci);
+  }
   // activation + operand store (the sum is complete)
   template <int N>
   TAMF_DEV void act_store(int a, int gr, int gn, float (&v)[N], float& am) const {
@@ -223,6 +267,7 @@ struct EpiQK {
   float qscale;
   int act;  // (ACT_NONE; the register epilogue dispatches on it)
   EpiCtl ctl;
+  static constexpr bool ROWSTATS = false;
   static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;
@@ -244,6 +289,7 @@ struct EpiVt {
   int H, hd, Skp;
   int act;
   EpiCtl ctl;
+  static constexpr bool ROWSTATS = false;
   static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
   static constexpr bool TRANSPOSED = true;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;  // (of one store_keys)
@@ -259,7 +305,8 @@ struct EpiVt {
 
 // in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed
 // per (clip, head): Vt[((b*H + h)*hd + e)][s], keys contiguous (what the P.V MFMA wants as its K axis).
-template <class Op>
+// LN = true: deferred LayerNorm of the input rows (see EpiBiasAct): bias = c2, c1 = column sums of the gamma-folded in_proj weight.
+template <class Op, bool LN = false>
 struct EpiQKV {
   const float* bias;  // [3d]
   typename Op::elem_t* qk;
@@ -267,17 +314,27 @@ struct EpiQKV {
   int d, H, hd, Sp, Skp;
   float qscale;
   EpiCtl ctl;
+  const float* c1 = nullptr;  // [3d] (LN)
+  LnStats ln{};
+  static constexpr bool ROWSTATS = LN;
+  // C element of tile row `row` -> projected value: acc ws + bias, or the row's deferred LayerNorm applied on the way
+  TAMF_DEV float proj(float acc, int row, float bb, float cc, float ws, const float2* rs) const {
+    if constexpr (LN) return aff(acc, row_aff(rs[row], ws), cc, bb);
+    else return fmaf(acc, ws, bb);
+  }
   template <int BM, int BN, int NT>
-  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs = nullptr) const {
     const float ws = ctl.wscale;
     if (n0 < 2 * d) {
       constexpr int VPR = BN / 8, RSTEP = NT / VPR;
       static_assert(NT % VPR == 0, "column group must be fixed per thread");
       const float sc = (n0 < d) ? qscale : 1.0f;
       const int col = (tid % VPR) * 8, gn = n0 + col;
-      float b[8];
+      float b[8], c[8];
       g_load8(bias + gn, b);
+      if constexpr (LN) g_load8(c1 + gn, c);
       settle(b);
+      if constexpr (LN) settle(c);
       float am = 0.f;
       // rows in batches of 4: the C-tile reads of a batch are requested together (one LDS latency per batch instead of one per row:
       // left to itself the loop is read - wait - convert - store, row by row)
@@ -290,8 +347,14 @@ struct EpiQKV {
         for (int i = 0; i < RB; ++i) {
           const int gr = m0 + tid / VPR + (r0 + i) * RSTEP;
           if (gr < M) {
+            if constexpr (LN) {
+              const RowAff ra = row_aff(rs[tid / VPR + (r0 + i) * RSTEP], ws);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = fmaf(v[i][j], ws, b[j]) * sc;
+              for (int j = 0; j < 8; ++j) v[i][j] = aff(v[i][j], ra, c[j], b[j]) * sc;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[i][j] = fmaf(v[i][j], ws, b[j]) * sc;
+            }
             Op::template store_rc<8>(qk, (long)gr * (2 * d) + gn, v[i], am);
           }
         }
@@ -306,10 +369,10 @@ struct EpiQKV {
         const int eg = n0 - 2 * d + col;
         const int h = eg / hd, e = eg % hd;
         const int b = gr0 / Sp, s0 = gr0 % Sp;
-        const float bb = bias[n0 + col];
+        const float bb = bias[n0 + col], cc = LN ? c1[n0 + col] : 0.f;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(Ct[(rg * 8 + j) * LDC + col], ws, bb);
+        for (int j = 0; j < 8; ++j) v[j] = proj(Ct[(rg * 8 + j) * LDC + col], rg * 8 + j, bb, cc, ws, rs);
         Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
       }
     } else {
@@ -334,13 +397,15 @@ struct EpiQKV {
         const int plane_off = (Op::SPLIT && piece >= 4) ? 64 : 0;
         const int ng = (M - m0 < BM ? M - m0 : BM) / 16;  // row groups of this tile that exist (M is a multiple of Sp)
         constexpr int NGRP = BN / FPW, NFG = (NGRP + NT / 64 - 1) / (NT / 64);  // feature groups of the tile / per wave
-        float bbs[NFG];
+        float bbs[NFG], ccs[NFG];
 #pragma unroll
         for (int i = 0; i < NFG; ++i) {
           const int fg = wv + i * (NT / 64);
           bbs[i] = bias[n0 + (fg < NGRP ? fg : 0) * FPW + f_lo];
+          ccs[i] = LN ? c1[n0 + (fg < NGRP ? fg : 0) * FPW + f_lo] : 0.f;
         }
         settle(bbs);
+        settle(ccs);
 #pragma unroll
         for (int i = 0; i < NFG; ++i) {
           const int fg = wv + i * (NT / 64);
@@ -348,7 +413,7 @@ struct EpiQKV {
           const int col = fg * FPW + f_lo;
           const int eg = n0 - 2 * d + col;
           const int h = eg / hd, e = eg % hd;
-          const float bb = bbs[i];
+          const float bb = bbs[i], cc = ccs[i];
           for (int r16 = 0; r16 < ng;) {
             const int gr = m0 + r16 * 16;
             const int b = gr / Sp, k16 = (gr % Sp) / 16;  // clip and 16-key group
@@ -357,10 +422,10 @@ struct EpiQKV {
             char* pp = (char*)vt + Op::byte_off(row_idx) + plane_off + q * 16;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaf(Ct[(r16 * 16 + 4 * q + j) * LDC + col], ws, bb);
+            for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(r16 * 16 + 4 * q + j) * LDC + col], r16 * 16 + 4 * q + j, bb, cc, ws, rs);
             if (pair) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 + j] = fmaf(Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col], ws, bb);
+              for (int j = 0; j < 4; ++j) v[4 + j] = proj(Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col], r16 * 16 + 16 + 4 * q + j, bb, cc, ws, rs);
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[4 + j] = 0.f;
@@ -396,10 +461,10 @@ struct EpiQKV {
           const int eg = n0 - 2 * d + col;
           const int h = eg / hd, e = eg % hd;
           const int b = gr0 / Sp, s0 = gr0 % Sp;
-          const float bb = bias[n0 + col];
+          const float bb = bias[n0 + col], cc = LN ? c1[n0 + col] : 0.f;
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaf(Ct[(row0 + j) * LDC + col], ws, bb);
+          for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(row0 + j) * LDC + col], row0 + j, bb, cc, ws, rs);
           Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
         }
       }
@@ -428,6 +493,7 @@ struct EpiSeqRows {
   int has_t, S;
   int t_off;             // steps since the counter was last written (position of this step inside its captured graph)
   EpiCtl ctl;
+  static constexpr bool ROWSTATS = false;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -502,6 +568,7 @@ struct EpiLN {
   typename Op::elem_t* xop;
   float eps;
   EpiCtl ctl;
+  static constexpr bool ROWSTATS = false;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     (void)n0;
@@ -614,15 +681,22 @@ struct EpiHead {
   // same-address atomics from 8 XCDs).
   int t_off;
   EpiCtl ctl;
+  // The last LayerNorm of the encoder, deferred into this GEMM (tamf_device.h): bias = c2, c1 = column sums of the gamma-folded head
+  // weight (XN floats; zeros when ln.part is null - f32, whose rows arrive normalised: (mean, rstd) = (0, 1) then gives
+  // fma(acc, ws, bias) bit for bit)
+  const float* ln_c1 = nullptr;
+  LnStats ln{};
+  static constexpr bool ROWSTATS = true;
   template <int BM, int BN, int NT>
-  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const { run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid); }
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs) const { run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, rs); }
   template <int BM, int BN, int NT>
-  TAMF_DEV void run_rows(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
+  TAMF_DEV void run_rows(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;
-    float bi[8];
+    float bi[8], ci[8];
     g_load8(bias + gn, bi);
+    g_load8(ln_c1 + gn, ci);
     float am = 0.f;
     for (int row = tid / VPR; row < BM; row += RSTEP) {
       const int gr = m0 + row;
@@ -632,18 +706,23 @@ struct EpiHead {
       const int tau = s - P;
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
+      {  // the head's projection itself: every mode below consumes v[j] = acc ws + bias (of the normalised row)
+        const RowAff ra = row_aff(rs[row], ctl.wscale);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = aff(v[j], ra, ci[j], bi[j]);
+      }
       if (mode == HEAD_X0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
-          if (c < F) x0_out[((long)b * F + c) * T + tau] = nan_to_num(fmaf(v[j], ctl.wscale, bi[j]));
+          if (c < F) x0_out[((long)b * F + c) * T + tau] = nan_to_num(v[j]);
         }
       } else if (mode == HEAD_RESIDUAL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
           const long o = ((long)b * T + tau) * F + c;
-          if (c < F) x0_out[o] = nan_to_num(x_in[o] + fmaf(v[j], ctl.wscale, bi[j]));
+          if (c < F) x0_out[o] = nan_to_num(x_in[o] + v[j]);
         }
       } else {
         const int ti = tcur[0] - t_off;
@@ -678,7 +757,7 @@ struct EpiHead {
         for (int j = 0; j < 8; ++j) {
           const int c = gn + j;
           if (c < F) {
-            const float x0 = nan_to_num(fmaf(v[j], ctl.wscale, bi[j]));
+            const float x0 = nan_to_num(v[j]);
             // mean = coef1*x0 + coef2*x_t ; sample = mean + [t!=0]*sigma*eps  (gaussian_diffusion.py:221-224,459)
             float r = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xt[j]));
             if (ti != 0) r = __fadd_rn(r, __fmul_rn(sg, ez[j]));
@@ -703,6 +782,7 @@ struct EpiStoreF32 {
   int ldo;
   int act;
   EpiCtl ctl;
+  static constexpr bool ROWSTATS = false;
   struct Cols {
     float bi[8];
     // a (free) register use that makes the compiler wait for the loads HERE, once: left to the first use inside a row loop,
@@ -765,6 +845,90 @@ struct EpiStoreF32 {
   }
 };
 
+// Residual add of a post-LN sublayer with the LayerNorm of its INPUT deferred (tamf_device.h, "Deferred LayerNorm"; 16-bit modes):
+//   u_next[m][n] = ((u[m][n] - mean[m]) rstd[m] gamma[n] + bb[n]) + C[m][n] ws            bb = beta + bias of this GEMM
+// read from and written back to the fp32 residual stream in place (every element by one lane), stored as the operand of the next
+// GEMM, and summarised per 32-column block as (S_b, Q_b) for the LayerNorm that the consumers of u_next will apply.
+// No LayerNorm in front (layer 0: the rows are the encoder's input): ln.part = null, gamma = ones, bb = bias.
+template <class Op>
+struct EpiResid {
+  const float* bb;           // [d]
+  const float* gamma;        // [d]
+  float* x;                  // [M][d]
+  typename Op::elem_t* xop;  // [M][d] operand planes
+  int d;
+  float2* part_out;          // [M][d / 32]
+  int act;                   // ACT_NONE (the register epilogue dispatches on it)
+  EpiCtl ctl;
+  LnStats ln{};
+  static constexpr bool ROWSTATS = true;
+  static_assert(Op::PREC != 0, "the deferred LayerNorm serves the 16-bit modes (f32 keeps the reference's operation order)");
+  static constexpr int LANE_CHUNK = 8;
+  static constexpr bool TRANSPOSED = false;
+  static constexpr int CHUNK_STORES = 2 + (Op::SPLIT ? 2 : 1) + 1;  // fp32 row piece (2 x 16 bytes), operand piece(s), block statistics
+  TAMF_DEV void flag(float am) const { Op::range_flag(am, ctl.status); }
+  template <int N>
+  TAMF_DEV void lane_cols_ln(int gn, float (&bi)[N], float (&ci)[N]) const {
+    g_loadn<N>(bb + gn, bi);
+    g_loadn<N>(gamma + gn, ci);
+  }
+  // one row piece of 8 columns from gn (a multiple of 8): v = the accumulators, u = the piece of the residual stream as it is.
+  // GROUPS: the 4 lanes that hold the 32-column block are the 4 lane groups of the wave (register epilogue) or a quad (LDS walk).
+  template <bool GROUPS>
+  TAMF_DEV void finish_piece(int gr, int gn, float (&v)[8], const float (&u)[8], const float (&bi)[8], const float (&ci)[8], float2 st,
+                             float& am) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float y = fmaf(__fmul_rn(__fsub_rn(u[j], st.x), st.y), ci[j], bi[j]);  // (the LayerNorm formula of every kernel here)
+      v[j] = fmaf(v[j], ctl.wscale, y);
+    }
+    const long o = (long)gr * d + gn;
+    g_store8(x + o, v);
+    Op::template store_rc<8>(xop, o, v, am);
+    const float2 p = ln_block_partial<GROUPS>(v);
+    if ((gn & 31) == 0) part_out[(long)gr * (d >> 5) + (gn >> 5)] = p;
+  }
+  template <int N>
+  TAMF_DEV void finish_ln(int, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&ci)[N], float2 st, float& am) const {
+    static_assert(N == 8, "row pieces of 8 columns");
+    float u[8];
+    g_load8(x + (long)gr * d + gn, u);
+    finish_piece<true>(gr, gn, v, u, bi, ci, st, am);
+  }
+  template <int BM, int BN, int NT>
+  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs) const {
+    constexpr int VPR = BN / 8, RSTEP = NT / VPR, NR = BM / RSTEP;
+    static_assert(NT % VPR == 0 && BM % RSTEP == 0 && VPR % 4 == 0, "a quad of threads = one 32-column block of one row");
+    const int col = (tid % VPR) * 8, gn = n0 + col;
+    float bi[8], ci[8];
+    g_load8(bb + gn, bi);
+    g_load8(gamma + gn, ci);
+    // every global load ahead of the first store (vmcnt retires in order)
+    float u[NR][8];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      int gr = m0 + tid / VPR + i * RSTEP;
+      gr = gr < M ? gr : M - 1;
+      g_load8(x + (long)gr * d + gn, u[i]);
+    }
+    settle(bi);
+    settle(ci);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) settle(u[i]);
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int row = tid / VPR + i * RSTEP, gr = m0 + row;
+      if (gr < M) {  // (uniform over the quad: its four threads share the row)
+        float v[8];
+        ct_load8(Ct, LDC, row, col, v);
+        finish_piece<false>(gr, gn, v, u[i], bi, ci, rs[row], am);
+      }
+    }
+    Op::range_flag(am, ctl.status);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // The kernel
 // ------------------------------------------------------------------------------------------------
@@ -794,7 +958,7 @@ TAMF_DEV int xcd_remap(int bid, int nblk) {
 // telling the compiler keeps its occupancy heuristics from squeezing the register budget
 template <int BM, int BN, int NWV>
 struct GemmOcc {
-  static constexpr int WG_PER_CU = (GemmSmem<BM, BN>::BYTES > 80 * 1024) ? 1 : 2;
+  static constexpr int WG_PER_CU = (GemmSmem<BM, BN>::TOTAL > 80 * 1024) ? 1 : 2;
   static constexpr int WAVES_PER_SIMD = (WG_PER_CU * NWV / 4) > 0 ? (WG_PER_CU * NWV / 4) : 1;
 };
 
@@ -900,6 +1064,9 @@ TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, co
   const bool abl_noload = (TAMF_ABL(ga.krot) & 0x1000) != 0, abl_nocomp = (TAMF_ABL(ga.krot) & 0x2000) != 0;
   const int rot = krs ? (int)(((unsigned)lb * (unsigned)krs) % (unsigned)KT) : 0;
   TAMF_ISSUE_ALL(rot, 0)
+  // deferred LayerNorm: (mean, rstd) of the tile's rows, staged behind the staging buffers while the first K tile is in flight
+  float2* const rstat = (float2*)(smem + SM::STATS_OFF);
+  if constexpr (Epi::ROWSTATS) ln_stage<NT>(epi.ln, m0, BM, M, rstat, tid);
   __syncthreads();
   TAMF_TS(ts1);
 
@@ -961,7 +1128,8 @@ TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, co
     }
   __syncthreads();
   if (tsink == 0x9E3779B9u && ga.M < 0) Ct[0] = 1.0f;  // never true; keeps the touch loads from being optimised away
-  epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
+  if constexpr (Epi::ROWSTATS) epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid, rstat);
+  else epi.template run<BM, BN, NT>(Ct, SM::LDC, m0, n0, M, tid);
 #ifdef TAMF_TIMELINE
   if (tid == 0 && bid < 8192) {
     unsigned long long* o = g_gemm_ts + bid * 5;

@@ -101,7 +101,10 @@ struct ClipCfg {
   static constexpr int NSTAGE = (3 * STAGE <= 160 * 1024) ? 3 : 2;
   // + a lane-private scratch row tile per wave (16 bytes x NI per lane) for the rolled form of an epilogue with an activation
   static constexpr int SCRATCH_OFF = NSTAGE * STAGE, SCRATCH_WAVE = NI * 1024;
-  static constexpr int BYTES = SCRATCH_OFF + 8 * SCRATCH_WAVE;
+  // + (mean, rstd) of the tile's rows for the epilogues that normalise (deferred LayerNorm, tamf_device.h): two slots - the X waves
+  // stage the next tile's rows while the Y waves may still be storing this one's
+  static constexpr int STATS_OFF = SCRATCH_OFF + 8 * SCRATCH_WAVE;
+  static constexpr int BYTES = STATS_OFF + 2 * MT * 8;
   static_assert(BYTES <= 160 * 1024, "LDS budget");
   // LDS-DMA pieces per K tile of loader wave nq: PIECES_HI for nq < PIECES_REM, else PIECES_HI - 1
   static constexpr int PIECES_HI = (NPIECE + 3) / 4, PIECES_REM = NPIECE % 4 == 0 ? 4 : NPIECE % 4;
@@ -343,9 +346,11 @@ TAMF_DEV int clip_tile_of(int n_tiles, int round) {
 
 // Register epilogue of one wave: row tile mi of the wave -> row row0 + 16 mi of the clip; chunk c of the lane = columns
 // gn + 4 CH c .. + CH (column tile c for CH = 4, column tiles 2c and 2c + 1 for CH = 8)
+// (ci / rs: second column constants and the staged (mean, rstd) of the tile's rows - epilogues with Epi::ROWSTATS, deferred LayerNorm)
 template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                                  const float (&bi)[C::NCHUNK][C::CHUNK], float& am) {
+                                  const float (&bi)[C::NCHUNK][C::CHUNK], const float (&ci)[C::NCHUNK][C::CHUNK], const float2* rs,
+                                  float& am) {
   constexpr int CH = C::CHUNK;
 #pragma unroll
   for (int mi = 0; mi < MS; ++mi) {
@@ -356,7 +361,8 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
         float v[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) v[j] = acc[mi][c * (CH / 4) + j / 4][j % 4];
-        epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c], am);
+        if constexpr (Epi::ROWSTATS) epi.template finish_ln<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c], ci[c], rs[r], am);
+        else epi.template finish_act<CH>(ACT, m0 + r, gn + 4 * CH * c, v, bi[c], am);
       }
     }
   }
@@ -368,8 +374,8 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
 // lane: NI ds_write_b128 + NI ds_read_b128, conflict-free, no barrier), selected by a scalar branch.
 template <class C, int NI, int MS, int ACT, class Epi>
 TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                                     const float (&bi)[C::NCHUNK][C::CHUNK], char* slot /* wave scratch + 16 * lane */,
-                                     float& am, bool one_row = false) {
+                                     const float (&bi)[C::NCHUNK][C::CHUNK], const float (&ci)[C::NCHUNK][C::CHUNK], const float2* rs,
+                                     char* slot /* wave scratch + 16 * lane */, float& am, bool one_row = false) {
   constexpr int CH = C::CHUNK;
 #pragma clang loop unroll(disable)
   for (int mi = 0; mi < MS; ++mi) {
@@ -389,26 +395,28 @@ TAMF_DEV void clip_store_rows_rolled(const Epi& epi, const f32x4 (&acc)[C::MSUB0
         float v[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) v[j] = a[c * (CH / 4) + j / 4][j % 4];
-        epi.template finish_act<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c], am);
+        if constexpr (Epi::ROWSTATS) epi.template finish_ln<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c], ci[c], rs[r], am);
+        else epi.template finish_act<CH>(ACT, one_row ? m0 : m0 + r, gn + 4 * CH * c, v, bi[c], am);
       }
     }
   }
 }
 template <class C, int NI, int MS, class Epi>
 TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int row0, int Sp, int m0, int gn,
-                              const float (&bi)[C::NCHUNK][C::CHUNK], int abl, char* slot) {
+                              const float (&bi)[C::NCHUNK][C::CHUNK], const float (&ci)[C::NCHUNK][C::CHUNK], const float2* rs, int abl,
+                              char* slot) {
   float am = 0.f;  // range accumulator of the operand stores (Op::store_rc), flagged once per tile and wave
   if (abl & 24) {  // (benchmark ablations: 8 = no activation, 16 = every row of the tile is stored into the clip's first row)
-    if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, am, (abl & 16) != 0);
-    else clip_store_rows_rolled<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, slot, am, (abl & 16) != 0);
+    if (epi.act == ACT_GELU && !(abl & 8)) clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, ci, rs, slot, am, (abl & 16) != 0);
+    else clip_store_rows_rolled<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, ci, rs, slot, am, (abl & 16) != 0);
     return;
   }
   if (epi.act == ACT_GELU) {
-    clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, slot, am);
+    clip_store_rows_rolled<C, NI, MS, ACT_GELU>(epi, acc, row0, Sp, m0, gn, bi, ci, rs, slot, am);
   } else if (epi.act == ACT_SILU) {
-    clip_store_rows_rolled<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi, slot, am);
+    clip_store_rows_rolled<C, NI, MS, ACT_SILU>(epi, acc, row0, Sp, m0, gn, bi, ci, rs, slot, am);
   } else {
-    clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, am);
+    clip_store_rows_act<C, NI, MS, ACT_NONE>(epi, acc, row0, Sp, m0, gn, bi, ci, rs, am);
   }
   epi.flag(am);
 }
@@ -534,6 +542,8 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int w_frag = (C::MT + wn0 + lr) * BKB;
   const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
   char* slot = smem + C::SCRATCH_OFF + wave * C::SCRATCH_WAVE + lane * 16;
+  float2* const rstat = (float2*)(smem + C::STATS_OFF);  // [2][MT] (mean, rstd) of the rows of the tile of round r: slot r & 1
+  static_assert(!(TR && Epi::ROWSTATS), "the transposed epilogue has no deferred-LayerNorm form");
 
   // The workgroup is persistent over its tiles (rounds of the grid) and treats their K tiles as ONE stream: interval j
   // belongs to K tile j % KT of round j / KT and lives in stage j % NS.  X multiplies K tile j in interval j and requests K tile
@@ -560,6 +570,11 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     for (int mi = 0; mi < C::MSUBX; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (Epi::ROWSTATS) {  // (mean, rstd) of the first tile's rows, while its first K tiles are in flight
+      int base, rows;
+      clip_part(ga, clip_tile_of(ga.n_tiles, 0) / ntn, base, rows);
+      ln_stage<256>(epi.ln, base, rows, base + rows, rstat, tid);
+    }
     // K tile 0 has landed: everything but the LA - 1 requests behind it
     if constexpr (LA == 2) {
       if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
@@ -614,6 +629,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         // column constants, then the next interval's requests (the epilogue must not delay them; and vmcnt retires in order: the
         // constants are waited for with the requests still in flight), then the rows
         float bi[C::NCHUNK][C::CHUNK];
+        float ci[C::NCHUNK][C::CHUNK];
         float bb[NI];
         if constexpr (TR) {
 #pragma unroll
@@ -621,7 +637,8 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
         } else {
 #pragma unroll
           for (int c = 0; c < C::NCHUNK; ++c) {
-            if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            if constexpr (Epi::ROWSTATS) epi.template lane_cols_ln<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c], ci[c]);
+            else if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
             else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
           }
         }
@@ -634,9 +651,11 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
         } else {
           clip_settle(bi);
+          if constexpr (Epi::ROWSTATS) clip_settle(ci);
           int base, rows;
           clip_part(ga, b, base, rows);
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
+          if (!(TAMF_ABL(ga.abl) & 4))
+            clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round & 1) * C::MT, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBX; ++mi)
@@ -644,6 +663,13 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         kt = 0;
         t = clip_tile_of(ga.n_tiles, ++round);
+        if constexpr (Epi::ROWSTATS) {  // the next tile's row statistics into the other slot (Y may still be reading this tile's)
+          if (t >= 0) {
+            int base, rows;
+            clip_part(ga, t / ntn, base, rows);
+            ln_stage<256>(epi.ln, base, rows, base + rows, rstat + (round & 1) * C::MT, tid);
+          }
+        }
       }
     }
   } else {
@@ -686,15 +712,19 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
         } else {
           float bi[C::NCHUNK][C::CHUNK];
+          float ci[C::NCHUNK][C::CHUNK];
 #pragma unroll
           for (int c = 0; c < C::NCHUNK; ++c) {
-            if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
+            if constexpr (Epi::ROWSTATS) epi.template lane_cols_ln<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c], ci[c]);
+            else if (TAMF_ABL(ga.abl) & 32) { for (int j = 0; j < C::CHUNK; ++j) bi[c][j] = 0.f; }  // (ablation: no column constants)
             else epi.template lane_cols<C::CHUNK>(n0 + lane_col + 4 * C::CHUNK * c, bi[c]);
           }
           clip_settle(bi);
+          if constexpr (Epi::ROWSTATS) clip_settle(ci);
           int base, rows;
           clip_part(ga, b, base, rows);
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, TAMF_ABL(ga.abl), slot);
+          if (!(TAMF_ABL(ga.abl) & 4))
+            clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round & 1) * C::MT, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBY; ++mi)

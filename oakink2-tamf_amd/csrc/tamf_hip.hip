@@ -19,7 +19,9 @@
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
+#ifdef TAMF_BENCH  // the row-block LayerNorm GEMM of round 4 (measured, not faster: DESIGN.md): an A/B partner of the measurement builds only
 #include "tamf_gemm_rowblock.h"
+#endif
 #include "tamf_geom.h"
 #include "tamf_misc.h"
 
@@ -45,6 +47,10 @@ struct OperandBuf {
 
 struct LayerW {
   OperandBuf Win, Wout, W1, W2;
+  // deferred LayerNorm (16-bit modes; tamf_device.h): Win / W1 hold gamma-folded weights, the consumers take (c1, c2) in place of the
+  // bias, the residual adds take (gamma, beta + bias) of the LayerNorm their residual passes through
+  float *c1_in = nullptr, *c2_in = nullptr, *c1_ff = nullptr, *c2_ff = nullptr;
+  float *g_att = nullptr, *bb_att = nullptr, *g_ffn = nullptr, *bb_ffn = nullptr;
   float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
@@ -117,6 +123,10 @@ struct tamf_ctx {
   unsigned* status = nullptr;  // this context's sticky status word (tamf_device.h): written by its kernels only
   unsigned char* side_dev = nullptr;
   int* objnum_dev = nullptr;  // per-clip object counts of tamf_set_cond_ragged
+  // deferred LayerNorm: partial row statistics of the residual stream after the attention / feed-forward sublayer, [Mmax][d / 32]
+  bool defer_ln = false;
+  float2 *stat_att = nullptr, *stat_ffn = nullptr;
+  float *c1_head = nullptr, *zeros_xn = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
@@ -203,8 +213,12 @@ static inline float h_bf2f(uint16_t h) {
 
 // upload host fp32 [N][K] as an operand matrix [N][ldk] in precision `prec` (cols >= K zero; ldk % 32 == 0).
 // bf16x3 rows are 128-byte groups of 32 elements: [hi: 32 bf16 | lo: 32 bf16] (tamf_device.h "Operand traits").
-static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what) {
+// rowsum (optional): per output row, the sum over K of the values AS STORED (after rounding to the operand format) - the c1 vector of
+// a GEMM behind a deferred LayerNorm must cancel the mean against exactly what the MFMAs multiply
+static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what,
+                          std::vector<double>* rowsum = nullptr) {
   const size_t n = (size_t)N * ldk;
+  if (rowsum) rowsum->assign(N, 0.0);
   if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
   int wexp = 0;  // f16x3: the tensor is stored as w * 2^wexp
   out->inv_scale = 1.0f;
@@ -233,12 +247,18 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
     for (int r = 0; r < N; ++r) memcpy(&h[(size_t)r * ldk], &w[(size_t)r * K], (size_t)K * 4);
+    if (rowsum)
+      for (int r = 0; r < N; ++r)
+        for (int k = 0; k < K; ++k) (*rowsum)[r] += w[(size_t)r * K + k];
     return dev_upload(ctx, (float**)&out->p, h.data(), n);
   }
   if (prec == TAMF_PREC_BF16) {
     std::vector<uint16_t> h(n, 0);
     for (int r = 0; r < N; ++r)
-      for (int k = 0; k < K; ++k) h[(size_t)r * ldk + k] = h_f2bf(w[(size_t)r * K + k]);
+      for (int k = 0; k < K; ++k) {
+        h[(size_t)r * ldk + k] = h_f2bf(w[(size_t)r * K + k]);
+        if (rowsum) (*rowsum)[r] += h_bf2f(h[(size_t)r * ldk + k]);
+      }
     return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n);
   }
   std::vector<uint16_t> h(n * 2, 0);
@@ -252,10 +272,12 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
         const _Float16 hi = (_Float16)vs, lo = (_Float16)(vs - (float)hi);
         memcpy(&h[o], &hi, 2);
         memcpy(&h[o + 32], &lo, 2);
+        if (rowsum) (*rowsum)[r] += std::ldexp((double)(float)hi + (double)(float)lo, -wexp);
       } else {
         const uint16_t hi = h_f2bf(v);
         h[o] = hi;
         h[o + 32] = h_f2bf(v - h_bf2f(hi));
+        if (rowsum) (*rowsum)[r] += (double)h_bf2f(h[o]) + (double)h_bf2f(h[o + 32]);
       }
     }
   return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * 2);
@@ -283,7 +305,7 @@ static int g_wg_slots = 512;
 
 template <class Op, int BM, int BN, class Epi, bool CAN_SPLIT = false>
 struct GemmLaunch {
-  static constexpr int SMEM = GemmSmem<BM, BN>::BYTES;
+  static constexpr int SMEM = GemmSmem<BM, BN>::TOTAL;
   // wave grid: the 64-row LayerNorm tiles own a CU and run 8 waves (2 x 4), the 64 x 512 one 16 waves (2 x 8: four waves
   // per SIMD cover each other's LDS / barrier latency, 36.6 -> 35.1 us for out-proj); the 128 x 128 tiles run 8 waves
   // (4 x 2) with two workgroups per CU
@@ -352,8 +374,8 @@ struct GemmLaunch {
 };
 // the wide-N GEMMs (QKV, FFN1, input merge) may split their left-over tiles
 template <class Epi> struct EpiCanSplit { static constexpr bool value = false; };
-template <class Op> struct EpiCanSplit<EpiBiasAct<Op>> { static constexpr bool value = true; };
-template <class Op> struct EpiCanSplit<EpiQKV<Op>> { static constexpr bool value = true; };
+template <class Op, bool LN> struct EpiCanSplit<EpiBiasAct<Op, LN>> { static constexpr bool value = true; };
+template <class Op, bool LN> struct EpiCanSplit<EpiQKV<Op, LN>> { static constexpr bool value = true; };
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
 
 // Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip of NSUB MFMA row tiles.  NSUB = 13 serves the bench shape (T = 196:
@@ -457,6 +479,7 @@ static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st
   }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
+#ifdef TAMF_BENCH
 // Row-block kernel (tamf_gemm_rowblock.h): rows per workgroup = the smallest of 32 / 48 / 64 that still fits one round of the CUs
 // (fewer rows per workgroup = more CUs busy and less MFMA work behind the same weight stream); beyond one round: 64
 template <class Op, int MI>
@@ -487,6 +510,12 @@ static hipError_t rowblock_launch(const GemmArgs<Op>& ga, const void* packed, co
   if ((ga.M + 47) / 48 <= cus) return rowblock_launch1<Op, 3>(ra, epi, st);
   return rowblock_launch1<Op, 4>(ra, epi, st);
 }
+#else
+template <class Op>
+static bool rowblock_applies(const GemmArgs<Op>&, const void*) { return false; }
+template <class Op>
+static hipError_t rowblock_launch(const GemmArgs<Op>&, const void*, const EpiLN<Op>&, hipStream_t) { return hipErrorNotSupported; }
+#endif
 template <class Op>
 static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st, const void* packed = nullptr) {
   if (rowblock_applies<Op>(ga, packed)) return rowblock_launch<Op>(ga, packed, epi, st);
@@ -507,6 +536,11 @@ static hipError_t prepare_clip() {
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::prepare()) != hipSuccess) return e;
+  if constexpr (Op::PREC != 0) {  // deferred LayerNorm: FFN1 with the row statistics, the two residual GEMMs
+    if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::prepare()) != hipSuccess) return e;
+  }
   if constexpr (Op::PREC == 0 || NS == 13) {  // the QKV projection on clip tiles: f32 (the 16-bit modes: A/B partner at T = 196 only)
     if ((e = ClipLaunch<Op, 2, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
     if ((e = ClipLaunch<Op, 4, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
@@ -522,6 +556,11 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32, true>::prepare()) != hipSuccess) return e;
+  if constexpr (Op::PREC != 0) {
+    if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
+    if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
+    if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  }
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
@@ -567,14 +606,18 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
   {
     if (!(g_sel & 512)) {
 #define TAMF_TRY_RES(HD_, NKB_)                                                                            \
-  if (hd == HD_ && AttnRes<Op, HD_, NKB_>::fits(aa.S, aa.Sp)) {                                           \
+  if (hd == HD_ && AttnRes<Op, HD_, NKB_>::fits(aa.S, aa.Sp) && nw <= AttnRes<Op, HD_, NKB_>::MAXW) {     \
     int lds = AttnRes<Op, HD_, NKB_>::smem(aa.S, aa.Sp);                                                   \
     AttnArgs<Op> a2 = aa;                                                                                  \
     int nwl = nw;                                                                                          \
     /* f32, a clip of 4 n + 1 query tiles (13 at T = 196): its last tile is key-split over four waves (tamf_attn.h) - decided by */ \
     /* the clip's length alone, so that a clip's result does not depend on the batch size or the query split.  f32 only: the    */ \
     /* 16-bit modes' waves overlap on a SIMD, the split buys them nothing at B = 64 and costs 1 - 3 % at B <= 32                 */ \
-    if (TAMF_ATTN_KSPLIT && Op::PREC == 0 && nqt % 4 == 1 && nqt >= 5) {                                   \
+    /* (whether the split applies is decided on the WORST case of the query split - one workgroup, nqt - 1 tile-owning waves: the  */ \
+    /*  partial area grows with them and the four extra waves then sit at nqt + 3 - so it cannot apply at one batch size and not  */ \
+    /*  at another)                                                                                                     */ \
+    if (TAMF_ATTN_KSPLIT && Op::PREC == 0 && nqt % 4 == 1 && nqt >= 5 && nqt + 3 <= AttnRes<Op, HD_, NKB_>::MAXW &&            \
+        AttnRes<Op, HD_, NKB_>::ksplit_extra(aa.S, aa.Sp, nqt - 1) >= 0) {                                 \
       const int nwq = (nqt - 1 + chunks - 1) / chunks, nlast = nqt - 1 - (chunks - 1) * nwq > 0 ? nqt - 1 - (chunks - 1) * nwq : 0; \
       /* the four key-split waves go to the SIMDs with the fewest tiles in the last workgroup (wave w runs on SIMD w mod 4) */     \
       const int r = nlast % 4, nlight = r ? 4 - r : 4;                                                     \
@@ -586,7 +629,7 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
         used |= 1 << idx; hw |= idx << (4 * j); if (idx + 1 > top) top = idx + 1;                          \
       }                                                                                                    \
       const int extra = AttnRes<Op, HD_, NKB_>::ksplit_extra(aa.S, aa.Sp, nwq);                            \
-      if (extra >= 0 && top <= 16) { a2.ksplit = 1; a2.nwq = nwq; a2.hw = hw; nwl = top; lds += extra; }   \
+      if (extra >= 0 && top <= AttnRes<Op, HD_, NKB_>::MAXW) { a2.ksplit = 1; a2.nwq = nwq; a2.hw = hw; nwl = top; lds += extra; } \
     }                                                                                                      \
     hipLaunchKernelGGL((attn_res_kernel<Op, HD_, NKB_>), grid, dim3(nwl * 64), lds, st, a2);               \
     return hipGetLastError();                                                                              \
@@ -678,6 +721,10 @@ static int alloc_workspaces(tamf_ctx* ctx, int max_batch, int max_frames) {
   A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
   A(dev_alloc(ctx, (void**)&ctx->objnum_dev, (long)max_batch * 4, true));
+  if (ctx->defer_ln) {
+    A(dev_alloc(ctx, (void**)&ctx->stat_att, Mmax * (d / 32) * 8, true));
+    A(dev_alloc(ctx, (void**)&ctx->stat_ffn, Mmax * (d / 32) * 8, true));
+  }
   A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
 #undef A
   g_alloc_tag = "(weights / tables)";
@@ -723,6 +770,7 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   ctx->P = arch->kind == TAMF_KIND_G ? 5 : 3;
   ctx->XK = arch->kind == TAMF_KIND_G ? 128 : round_up(arch->input_dim + arch->h2o_dim, 64);
   ctx->EB = precision == TAMF_PREC_BF16 ? 2 : 4;
+  ctx->defer_ln = precision != TAMF_PREC_F32;  // f32 keeps the reference's operation order (LayerNorm where the reference has it)
   ctx->layers.resize(ctx->L);
 
   auto bail = [&](int rc) {
@@ -796,11 +844,13 @@ extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_fra
   ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = ctx->etmp = ctx->meanbuf = ctx->objfeat = ctx->tmp32 = nullptr;
   ctx->xs_op = ctx->h1_op = ctx->X_op = ctx->QK_op = ctx->Vt_op = ctx->A_op = ctx->H_op = OperandBuf{};
   ctx->X_st = ctx->xs_st = nullptr;
+  ctx->stat_att = ctx->stat_ffn = nullptr;
   ctx->cond_set = false;
   ctx->B = ctx->T = ctx->S = ctx->Sp = ctx->Skp = ctx->M = 0;
   return alloc_workspaces(ctx, max_batch, max_frames);
 }
 
+#ifdef TAMF_BENCH
 // fragment-major copy of a [512][K] operand matrix (tamf_gemm_rowblock.h)
 static int pack_rowblock(tamf_ctx* ctx, OperandBuf* ob, int K, hipStream_t st) {
   const size_t bytes = (size_t)512 * K * ctx->EB;
@@ -810,6 +860,7 @@ static int pack_rowblock(tamf_ctx* ctx, OperandBuf* ob, int K, hipStream_t st) {
   HIPCHK(ctx, hipGetLastError());
   return 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // weights
@@ -893,14 +944,60 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   for (int l = 0; l < ctx->L; ++l) {
     const std::string p = "seqTransEncoder.layers." + std::to_string(l);
     LayerW& w = ctx->layers[l];
-    TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win, (p + ".self_attn.in_proj_weight").c_str()));
+    if (ctx->defer_ln) {
+      // Deferred LayerNorm: fold the gain of the LayerNorm in front of a GEMM into its weight (W' = W diag(gamma)), c1 = W' 1 over the
+      // values as stored, c2 = W beta + bias (fp64); the residual adds take gamma and beta + bias of the LayerNorm their residual input
+      // passes through.  Layer 0's attention block reads the encoder input itself: identity (gamma 1, beta 0).
+      const std::string pp = "seqTransEncoder.layers." + std::to_string(l - 1);
+      const float* g_in = l ? R(pp + ".norm2.weight") : nullptr;   // LayerNorm in front of this layer's attention block
+      const float* be_in = l ? R(pp + ".norm2.bias") : nullptr;
+      const float* g1 = R(p + ".norm1.weight");                    // ... in front of its feed-forward block
+      const float* be1 = R(p + ".norm1.bias");
+      auto fold = [&](const float* W, const float* bias, int N, const float* g, const float* be, OperandBuf* ob, float** c1, float** c2,
+                      const std::string& what) -> int {
+        std::vector<float> wf((size_t)N * d), v1(N), v2(N);
+        std::vector<double> rs;
+        for (int n = 0; n < N; ++n) {
+          double acc = bias[n];
+          for (int k = 0; k < d; ++k) {
+            wf[(size_t)n * d + k] = g ? W[(size_t)n * d + k] * g[k] : W[(size_t)n * d + k];
+            if (be) acc += (double)W[(size_t)n * d + k] * be[k];
+          }
+          v2[n] = (float)acc;
+        }
+        TRY(upload_operand(ctx, prec, wf.data(), N, d, d, ob, what.c_str(), &rs));
+        for (int n = 0; n < N; ++n) v1[n] = g ? (float)rs[n] : 0.f;  // (no LayerNorm in front: the mean term is zero anyway)
+        TRY(dev_upload(ctx, c1, v1.data(), v1.size()));
+        return dev_upload(ctx, c2, v2.data(), v2.size());
+      };
+      TRY(fold(R(p + ".self_attn.in_proj_weight"), R(p + ".self_attn.in_proj_bias"), 3 * d, g_in, be_in, &w.Win, &w.c1_in, &w.c2_in,
+               p + ".self_attn.in_proj_weight"));
+      TRY(fold(R(p + ".linear1.weight"), R(p + ".linear1.bias"), ff, g1, be1, &w.W1, &w.c1_ff, &w.c2_ff, p + ".linear1.weight"));
+      std::vector<float> ga(d), bb(d);
+      for (int n = 0; n < d; ++n) {
+        ga[n] = g_in ? g_in[n] : 1.0f;
+        bb[n] = (be_in ? be_in[n] : 0.0f) + R(p + ".self_attn.out_proj.bias")[n];
+      }
+      TRY(dev_upload(ctx, &w.g_att, ga.data(), ga.size()));
+      TRY(dev_upload(ctx, &w.bb_att, bb.data(), bb.size()));
+      for (int n = 0; n < d; ++n) {
+        ga[n] = g1[n];
+        bb[n] = be1[n] + R(p + ".linear2.bias")[n];
+      }
+      TRY(dev_upload(ctx, &w.g_ffn, ga.data(), ga.size()));
+      TRY(dev_upload(ctx, &w.bb_ffn, bb.data(), bb.size()));
+    } else {
+      TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win, (p + ".self_attn.in_proj_weight").c_str()));
+      TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
+    }
     TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout, (p + ".self_attn.out_proj.weight").c_str()));
-    TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2, (p + ".linear2.weight").c_str()));
+#ifdef TAMF_BENCH
     if (d == 512 && (g_sel & 2048)) {  // fragment-major copies for the row-block LayerNorm GEMMs (A/B selection, set BEFORE the weights are finalised)
       TRY(pack_rowblock(ctx, &w.Wout, d, st));
       TRY(pack_rowblock(ctx, &w.W2, ff, st));
     }
+#endif
     TRY(upload_f32(ctx, p + ".self_attn.in_proj_bias", &w.b_in));
     TRY(upload_f32(ctx, p + ".self_attn.out_proj.bias", &w.b_out));
     TRY(upload_f32(ctx, p + ".linear1.bias", &w.b1));
@@ -948,11 +1045,27 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2, "input_merge.2.weight"));
   TRY(upload_f32(ctx, "input_merge.2.bias", &ctx->bm2));
   {
-    std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f);
+    std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f), c1h(ctx->XN, 0.f);
     memcpy(wf.data(), R("output_process.poseFinal.weight"), (size_t)F * d * 4);
     memcpy(bfp.data(), R("output_process.poseFinal.bias"), (size_t)F * 4);
-    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf, "output_process.poseFinal.weight"));
+    std::vector<double> rs;
+    if (ctx->defer_ln) {  // the encoder's last LayerNorm, deferred into the head: W_f diag(gamma), c1, c2 = W_f beta + b_f
+      const std::string pl = "seqTransEncoder.layers." + std::to_string(ctx->L - 1);
+      const float *g = R(pl + ".norm2.weight"), *be = R(pl + ".norm2.bias");
+      for (int n = 0; n < F; ++n) {
+        double acc = bfp[n];
+        for (int k = 0; k < d; ++k) {
+          acc += (double)wf[(size_t)n * d + k] * be[k];
+          wf[(size_t)n * d + k] *= g[k];
+        }
+        bfp[n] = (float)acc;
+      }
+    }
+    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf, "output_process.poseFinal.weight", &rs));
+    if (ctx->defer_ln)
+      for (int n = 0; n < F; ++n) c1h[n] = (float)rs[n];
     TRY(dev_upload(ctx, &ctx->bf, bfp.data(), bfp.size()));
+    TRY(dev_upload(ctx, &ctx->c1_head, c1h.data(), c1h.size()));
   }
   TRY(upload_f32(ctx, "sequence_pos_encoder.pe", &ctx->pe));
   TRY(upload_f32(ctx, "hand_shape_process.shape_embed.weight", &ctx->Wshape));
@@ -1110,6 +1223,22 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
 // ------------------------------------------------------------------------------------------------
 // one denoiser evaluation = the kernel sequence below (captured into a hipGraph by the sampling loop)
 // ------------------------------------------------------------------------------------------------
+// residual GEMM of the deferred-LayerNorm form (out-proj, FFN2; 16-bit modes): the clip's row parts where whole clips would fill at
+// most half of the CUs, whole-clip tiles where they fill at least half of their rounds' slots, 128 x 128 tiles for every other shape -
+// the same K order per element and the same statistics trees in all three, i.e. the same bits
+template <class Op>
+static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, int B, int Sp, hipStream_t st) {
+  if (!(g_sel & 2)) {
+    TAMF_CLIP_NSUB(Sp, {
+      if (ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::applies_parts(B, Sp, ga.N, ga.K))
+        return ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::launch(nullptr, ga.A, ga.lda, ga.W, ga.ldw, B, Sp, ga.N, ga.K, ep, st);
+      if (ClipLaunch<Op, 2, EpiResid<Op>, NS>::applies(B, Sp, ga.N, ga.K, 50))
+        return ClipLaunch<Op, 2, EpiResid<Op>, NS>::launch(nullptr, ga.A, ga.lda, ga.W, ga.ldw, B, Sp, ga.N, ga.K, ep, st);
+    })
+  }
+  return gemm128<Op>(ga, ep, st);
+}
+
 // second kernel of the two-kernel form of a LayerNorm-fused GEMM: X = LayerNorm(tmp32 + X) (+ operand)
 template <class Op>
 static void launch_residual_ln(tamf_ctx* ctx, const float* gamma, const float* beta, hipStream_t st) {
@@ -1153,6 +1282,59 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
+  bool deferred_done = false;
+  if constexpr (Op::PREC != 0) {
+    // Deferred LayerNorm (tamf_device.h): the residual stream X / X_op holds the UN-normalised sums; five launches per layer
+    if (ctx->defer_ln) {
+      const int NB = d / 32;
+      const float inv_d = 1.0f / (float)d;
+      for (int l = 0; l < ctx->L; ++l) {
+        LayerW& w = ctx->layers[l];
+        const LnStats ln_in{l ? ctx->stat_ffn : nullptr, NB, inv_d, 1e-5f};  // the LayerNorm in front of the attention block (layer 0: none)
+        const LnStats ln_ff{ctx->stat_att, NB, inv_d, 1e-5f};               // ... in front of the feed-forward block
+        {
+          GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
+          EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, w.c1_in, ln_in};
+          HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+          mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
+        }
+        {
+          AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H, 0};
+          HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
+          mark("attention", 4.0 * B * (double)S * S * dd);
+        }
+        {
+          GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
+          EpiResid<Op> ep{w.bb_att, w.g_att, ctx->X, (E*)ctx->X_st, d, ctx->stat_att, ACT_NONE, {w.Wout.inv_scale, ctx->status}, ln_in};
+          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, st));
+          mark("gemm_outproj", BS * 2.0 * dd * dd);
+        }
+        {
+          GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
+          EpiBiasAct<Op, true> ep{w.c2_ff, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}, w.c1_ff, ln_ff};
+          bool on_clip = false;
+          if (!(g_sel & 8)) {
+            TAMF_CLIP_NSUB(Sp, {
+              if (ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::applies(B, Sp, ff, d)) {
+                HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+                on_clip = true;
+              }
+            })
+          }
+          if (!on_clip) HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+          mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
+        }
+        {
+          GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
+          EpiResid<Op> ep{w.bb_ffn, w.g_ffn, ctx->X, (E*)ctx->X_st, d, ctx->stat_ffn, ACT_NONE, {w.W2.inv_scale, ctx->status}, ln_ff};
+          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, st));
+          mark("gemm_ffn2", BS * 2.0 * dd * ff);
+        }
+      }
+      deferred_done = true;
+    }
+  }
+  if (!deferred_done)
   for (int l = 0; l < ctx->L; ++l) {
     const LayerW& w = ctx->layers[l];
     {
@@ -1314,6 +1496,8 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.n_steps = ctx->n_steps;
   h.lp = ctx->loop_params;
   h.ctl = EpiCtl{ctx->Wf.inv_scale, ctx->status};
+  h.ln_c1 = ctx->c1_head;  // (zeros in f32)
+  h.ln = LnStats{ctx->defer_ln ? ctx->stat_ffn : nullptr, ctx->d / 32, 1.0f / (float)ctx->d, 1e-5f};
   return h;
 }
 
@@ -1640,11 +1824,13 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   if (ln) {
     EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, 1e-5f};
     char* packed = nullptr;
+#ifdef TAMF_BENCH
     if (N == 512) {  // the row-block kernel reads a fragment-major copy of the weights (what tamf_finalize_weights prepares)
       packed = (char*)tb.get((size_t)N * Kp * Op::EB);
       if (!packed) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
       hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d((long)N * Kp * Op::EB / 16), dim3(256), 0, st, wo, Kp, Kp, packed);
     }
+#endif
     e = gemm_ln<Op>(ga, ep, st, packed);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
@@ -1771,11 +1957,13 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
   hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, 4u);
   GemmArgs<Op> ga{a, K, w, K, M, N, K, 0};
   char* wpacked = nullptr;
+#ifdef TAMF_BENCH
   if (epi_kind == 2 && N == 512) {
     wpacked = (char*)tb.get((size_t)wn * Op::EB);
     if (!wpacked) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
     hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d(wn * Op::EB / 16), dim3(256), 0, st, w, K, K, wpacked);
   }
+#endif
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
   hipError_t e = hipSuccess;

@@ -37,7 +37,7 @@ def kernels(path):
 
 
 def parse(name):
-    m = re.match(r"_Z16clip_gemm_kernelI\d+(Op[A-Z0-9]+)Li(\d+)ELi(\d+)ELi(\d+)E\d+(Epi[A-Za-z0-9]+?)(?:IS0_E)?Ev", name)
+    m = re.match(r"_Z16clip_gemm_kernelI\d+(Op[A-Z0-9]+)Li(\d+)ELi(\d+)ELi(\d+)E\d+(Epi[A-Za-z0-9]+?)(?:IS0_(?:Lb[01]E)?E)?Ev", name)
     if not m:
         raise IsaMismatch("cannot parse " + name)
     return m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5)
@@ -61,7 +61,9 @@ def expected(op, nsub, ni, xsub, epi):
             ch = 4 if prec == 0 else 8
             cs = ch // 4 + (2 if split else 1)
             hook = 2 + (2 if (split or prec == 0) else 1)
-        else:  # EpiBiasAct, EpiQK: operand output
+        elif epi == "EpiResid":  # deferred LayerNorm: fp32 row piece (2 x 16 bytes) + operand piece(s) + the block statistics (8 bytes)
+            ch, cs = 8, 2 + (2 if split else 1) + 1
+        else:  # EpiBiasAct (with or without the deferred LayerNorm of its rows), EpiQK: operand output
             ch, cs = (4 if prec == 0 else 8), (2 if split else 1)
         nchunk = 4 * ni // ch
         sx = msx * nchunk * cs
@@ -98,3 +100,38 @@ def check(path, log=None):
         raise IsaMismatch(f"{bad} of {n} clip_gemm_kernel instantiations do not match the store-count formula of tamf_gemm_clip.h:\n"
                           + "\n".join(l for l in report if l.startswith("BAD")))
     return n
+
+
+SCRATCH_LIMIT = 32  # bytes per lane
+
+
+def scratch_report(path, prefixes=("_Z15attn_res_kernel", "_Z11attn_kernel", "_Z16clip_gemm_kernel")):
+    """[(kernel, private segment bytes, vgprs)] of the hot kernels, from their .amdhsa_kernel descriptors.  Scratch in these kernels is
+    register spilling (none of them indexes a private array at run time): round 4 shipped short-clip attention instantiations with
+    880 - 1 048 bytes of it per lane, unnoticed."""
+    text = open(path).read()
+    out = []
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, body = m.group(1), m.group(2)
+        if not name.startswith(prefixes):
+            continue
+        ps = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        out.append((name, int(ps.group(1)) if ps else 0, int(vg.group(1)) if vg else -1))
+    return out
+
+
+def check_scratch(path, limit=SCRATCH_LIMIT, log=None):
+    """Raises IsaMismatch when an attention / clip-GEMM kernel keeps more than `limit` bytes of scratch per lane; returns the number of
+    kernels looked at."""
+    rep = scratch_report(path)
+    bad = [(n, ps, vg) for n, ps, vg in rep if ps > limit]
+    if log:
+        for n, ps, vg in rep:
+            if ps:
+                log(f"scratch {ps:5d} B  vgprs {vg:3d}  {n}")
+    if not rep:
+        raise IsaMismatch("no attention / clip-GEMM kernel descriptor found in " + path)
+    if bad:
+        raise IsaMismatch(f"{len(bad)} hot kernel(s) spill more than {limit} bytes per lane:\n" + "\n".join(f"  {ps} B ({vg} vgprs) {n}" for n, ps, vg in bad))
+    return len(rep)

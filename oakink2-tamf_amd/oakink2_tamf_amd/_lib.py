@@ -105,6 +105,12 @@ def _build_locked(hipcc: str, verbose: bool) -> str:
             n = _isa_check.check(asm)
             if verbose:
                 print(f"ISA check: all {n} clip_gemm_kernel instantiations match the counted waits")
+            try:  # register spilling in a hot kernel is a performance bug, not a correctness one: reported, never fatal
+                _isa_check.check_scratch(asm)
+            except _isa_check.IsaMismatch as e:
+                import warnings
+
+                warnings.warn(f"libtamf_hip: {e}")
         except (_isa_check.IsaMismatch, IndexError, KeyError, ValueError) as e:  # (a newer hipcc may also break the checker's parsing)
             import warnings
 

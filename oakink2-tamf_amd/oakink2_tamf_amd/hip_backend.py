@@ -226,6 +226,13 @@ class TamfContext:
             num_np = np.ascontiguousarray(torch.as_tensor(obj_num).cpu().numpy() if isinstance(obj_num, torch.Tensor) else obj_num, dtype=np.int32)
             if num_np.shape != (B,):
                 raise ValueError(f"obj_num must hold one count per clip: shape {num_np.shape} for B = {B}")
+        if num_np is None and not hasattr(lib(), "tamf_set_cond_ragged"):  # (an older A/B build loaded through _lib.load_from)
+            with torch.cuda.device(dev):
+                _check(lib().tamf_set_cond(self._h, B, T, nobj, c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),
+                                           c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()), c_void_p(ot.data_ptr()), c_void_p(_stream_ptr(dev))), self._h)
+            self._keep = [te, sh, oe, ot]
+            self.B, self.T = int(B), int(T)
+            return
         with torch.cuda.device(dev):
             _check(lib().tamf_set_cond_ragged(self._h, B, T, nobj, num_np.ctypes.data_as(c_void_p) if num_np is not None else c_void_p(0),
                                               c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),

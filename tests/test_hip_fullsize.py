@@ -593,8 +593,7 @@ def test_rowblock_ln_kernels_give_the_same_bits(full, full160, prec, B, T):
     finally:
         lib().tamf_set_gemm_tuning(-1)
     assert torch.equal(got, ref), (prec, B, T, float((got - ref).abs().max()))
-    if prec in ("f16x3", "bf16x3"):  # (the two-kernel FFN2 of the split modes' default path disappears: proof that the other kernels ran)
-        assert n_rb < n_default, (n_rb, n_default)
+    assert n_rb <= n_default, (n_rb, n_default)  # (round 5: the 16-bit modes run the deferred-LayerNorm form, which has no LayerNorm GEMM to replace)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])

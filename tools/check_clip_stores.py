@@ -39,6 +39,11 @@ def main():
     except _isa_check.IsaMismatch as e:
         raise SystemExit(str(e))
     print(f"all {n} clip_gemm_kernel instantiations match")
+    try:
+        k = _isa_check.check_scratch(path, log=print)
+    except _isa_check.IsaMismatch as e:
+        raise SystemExit(str(e))
+    print(f"no register spilling beyond {_isa_check.SCRATCH_LIMIT} bytes per lane in {k} attention / clip-GEMM kernels")
 
 
 if __name__ == "__main__":
