@@ -489,48 +489,67 @@ TAMF_DEV float2 ln_block_partial(const float (&v)[8]) {
 // (mean, rstd) of rows [r0, r0 + rows) into out[0 .. rows) (LDS), by NT threads, 4 lanes (a quad) per row: lane q of the quad takes the
 // blocks q NB/4 .. (q + 1) NB/4 - 1 in order, the quad combines as (q0 + q1) + (q2 + q3).  mean = S / d;
 // M2 = sum_b (Q_b + 32 (S_b / 32 - mean)^2); rstd = 1 / sqrt(M2 / d + eps).  Rows past row_limit are clamped (their value is never used).
-template <int NT>
-TAMF_DEV void ln_stage(const LnStats& s, int r0, int rows, int row_limit, float2* out, int tid) {
+// AFF: what a GEMM behind the LayerNorm needs per row is staged instead - (ra, rb) = (rstd ws, -(rstd mean)), so that its epilogue
+// is out = fma(acc, ra, fma(rb, c1[n], c2[n])) (tamf_gemm.h; ws = the power-of-two weight scale of the launch).
+// MAXP = passes of NT / 4 rows that cover the tile: the partials of ALL passes are requested before the first is combined (one
+// global-load latency per tile, not one per pass - the first form of this function cost the FFN1 launch 6 us).
+struct LnRaw {
+  float4 x, y;
+};
+template <int NT, bool AFF, int MAXP>
+TAMF_DEV void ln_stage(const LnStats& s, float ws, int r0, int rows, int row_limit, float2* out, int tid) {
 #pragma clang fp contract(off)
   static_assert(NT % 64 == 0, "whole waves");
-  const int q = tid & 3;
-  for (int r = tid >> 2; r < rows; r += NT / 4) {  // (a quad shares r: its four lanes enter and leave together, the DPP steps see all of them)
-    float2 res = make_float2(0.f, 1.f);
-    if (s.part) {
-      int gr = r0 + r;
+  constexpr int RPP = NT / 4;
+  const int q = tid & 3, rq = tid >> 2;
+  if (!s.part) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p)
+      if (q == 0 && rq + p * RPP < rows) out[rq + p * RPP] = AFF ? make_float2(ws, -0.0f) : make_float2(0.f, 1.f);
+    return;
+  }
+  const int nbq = s.NB >> 2;
+  LnRaw raw[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    raw[p].x = raw[p].y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p * RPP < rows) {  // (uniform)
+      int gr = r0 + rq + p * RPP;
       gr = gr < row_limit ? gr : row_limit - 1;
-      const int nbq = s.NB >> 2;
-      const float2* p = s.part + (long)gr * s.NB + q * nbq;
-      float sb[4], qb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sb[i] = qb[i] = 0.f;
+      const float2* ptr = s.part + (long)gr * s.NB + q * nbq;
       if (nbq == 4) {
-        const float4 x = *(const float4*)p, y = *(const float4*)(p + 2);
-        sb[0] = x.x; qb[0] = x.y; sb[1] = x.z; qb[1] = x.w; sb[2] = y.x; qb[2] = y.y; sb[3] = y.z; qb[3] = y.w;
+        raw[p].x = *(const float4*)ptr;
+        raw[p].y = *(const float4*)(ptr + 2);
       } else if (nbq == 2) {
-        const float4 x = *(const float4*)p;
-        sb[0] = x.x; qb[0] = x.y; sb[1] = x.z; qb[1] = x.w;
+        raw[p].x = *(const float4*)ptr;
       } else {
-        const float2 x = *p;
-        sb[0] = x.x; qb[0] = x.y;
+        const float2 t = *ptr;
+        raw[p].x = make_float4(t.x, t.y, 0.f, 0.f);
       }
-      float S = sb[0];
-#pragma unroll
-      for (int i = 1; i < 4; ++i)
-        if (i < nbq) S = S + sb[i];
-      S = ln_sum4<false>(S);
-      const float mean = S * s.inv_d;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < nbq) {
-          const float dm = sb[i] * 0.03125f - mean;
-          m2 = m2 + (qb[i] + 32.0f * (dm * dm));
-        }
-      m2 = ln_sum4<false>(m2);
-      res = make_float2(mean, 1.0f / sqrtf(m2 * s.inv_d + s.eps));
     }
-    if (q == 0 && r < rows) out[r] = res;
+  }
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    if (p * RPP >= rows) break;  // (uniform: the DPP steps below see whole quads)
+    const float sb[4] = {raw[p].x.x, raw[p].x.z, raw[p].y.x, raw[p].y.z};
+    const float qb[4] = {raw[p].x.y, raw[p].x.w, raw[p].y.y, raw[p].y.w};
+    float S = sb[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < nbq) S = S + sb[i];
+    S = ln_sum4<false>(S);
+    const float mean = S * s.inv_d;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nbq) {
+        const float dm = sb[i] * 0.03125f - mean;
+        m2 = m2 + (qb[i] + 32.0f * (dm * dm));
+      }
+    m2 = ln_sum4<false>(m2);
+    const float rstd = 1.0f / sqrtf(m2 * s.inv_d + s.eps);
+    const int r = rq + p * RPP;
+    if (q == 0 && r < rows) out[r] = AFF ? make_float2(rstd * ws, -(rstd * mean)) : make_float2(mean, rstd);
   }
 }
 

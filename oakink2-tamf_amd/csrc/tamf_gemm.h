@@ -82,13 +82,9 @@ TAMF_DEV void settle(const float (&v)[N]) {
   for (int j = 0; j < N; ++j) asm volatile("" ::"v"(v[j]));
 }
 // Deferred LayerNorm in front of a GEMM (tamf_device.h): out = rstd (acc ws - mean c1[n]) + c2[n] = fma(acc, ra, fma(rb, c1[n], c2[n])) with the row
-// terms ra = rstd ws, rb = -(rstd mean).  Explicit roundings: every kernel shape produces the same bits.  With (mean, rstd) = (0, 1)
-// - no LayerNorm in front - it is fma(acc, ws, c2[n]) bit for bit.
-struct RowAff {
-  float ra, rb;
-};
-TAMF_DEV RowAff row_aff(float2 st, float ws) { return RowAff{__fmul_rn(st.y, ws), -__fmul_rn(st.y, st.x)}; }
-TAMF_DEV float aff(float acc, const RowAff& a, float c1, float c2) { return fmaf(acc, a.ra, fmaf(a.rb, c1, c2)); }
+// terms ra = rstd ws, rb = -(rstd mean).  With (mean, rstd) = (0, 1) - no LayerNorm in front - it is fma(acc, ws, c2[n]) bit for bit.
+// The kernel stages (ra, rb) per row of the tile (ln_stage<.., true>): st.x = ra, st.y = rb.
+TAMF_DEV float aff(float acc, float2 st, float c1, float c2) { return fmaf(acc, st.x, fmaf(st.y, c1, c2)); }
 
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
   gst16f(p, v[0], v[1], v[2], v[3]);
@@ -110,6 +106,8 @@ struct EpiBiasAct {
   const float* c1 = nullptr;  // [N] (LN)
   LnStats ln{};
   static constexpr bool ROWSTATS = LN;
+  static constexpr bool STAGE_AFF = true;  // the kernel stages (ra, rb) per row
+  static constexpr bool PREFETCH = false;
   // Column constants of a thread (its 8 columns are the same for all its rows): loaded once per tile, ahead of the row
   // loops - a global load inside the row loop serialises the loop on L2 latency, and a load issued after stores waits for
   // them (vmcnt is in order), which is why the slab-wise epilogue of tamf_gemm_clip.h fetches these before its first slab
@@ -212,9 +210,8 @@ struct EpiBiasAct {
   // the same with the deferred LayerNorm of the row (st = its (mean, rstd)): bi = c2, ci = c1
   template <int N>
   TAMF_DEV void finish_ln(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&ci)[N], float2 st, float& am) const {
-    const RowAff ra = row_aff(st, ctl.wscale);
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = aff(v[j], ra, ci[j], bi[j]);
+    for (int j = 0; j < N; ++j) v[j] = aff(v[j], st, ci[j], bi[j]);
     act_store<N>(a, gr, gn, v, am);
   }
   template <int N>
@@ -268,6 +265,7 @@ struct EpiQK {
   int act;  // (ACT_NONE; the register epilogue dispatches on it)
   EpiCtl ctl;
   static constexpr bool ROWSTATS = false;
+  static constexpr bool PREFETCH = false;
   static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;
@@ -290,6 +288,7 @@ struct EpiVt {
   int act;
   EpiCtl ctl;
   static constexpr bool ROWSTATS = false;
+  static constexpr bool PREFETCH = false;
   static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
   static constexpr bool TRANSPOSED = true;
   static constexpr int CHUNK_STORES = Op::SPLIT ? 2 : 1;  // (of one store_keys)
@@ -317,9 +316,10 @@ struct EpiQKV {
   const float* c1 = nullptr;  // [3d] (LN)
   LnStats ln{};
   static constexpr bool ROWSTATS = LN;
+  static constexpr bool STAGE_AFF = true;
   // C element of tile row `row` -> projected value: acc ws + bias, or the row's deferred LayerNorm applied on the way
   TAMF_DEV float proj(float acc, int row, float bb, float cc, float ws, const float2* rs) const {
-    if constexpr (LN) return aff(acc, row_aff(rs[row], ws), cc, bb);
+    if constexpr (LN) return aff(acc, rs[row], cc, bb);
     else return fmaf(acc, ws, bb);
   }
   template <int BM, int BN, int NT>
@@ -348,7 +348,7 @@ struct EpiQKV {
           const int gr = m0 + tid / VPR + (r0 + i) * RSTEP;
           if (gr < M) {
             if constexpr (LN) {
-              const RowAff ra = row_aff(rs[tid / VPR + (r0 + i) * RSTEP], ws);
+              const float2 ra = rs[tid / VPR + (r0 + i) * RSTEP];
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[i][j] = aff(v[i][j], ra, c[j], b[j]) * sc;
             } else {
@@ -494,6 +494,7 @@ struct EpiSeqRows {
   int t_off;             // steps since the counter was last written (position of this step inside its captured graph)
   EpiCtl ctl;
   static constexpr bool ROWSTATS = false;
+  static constexpr bool PREFETCH = false;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
@@ -569,6 +570,7 @@ struct EpiLN {
   float eps;
   EpiCtl ctl;
   static constexpr bool ROWSTATS = false;
+  static constexpr bool PREFETCH = false;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
     (void)n0;
@@ -687,6 +689,7 @@ struct EpiHead {
   const float* ln_c1 = nullptr;
   LnStats ln{};
   static constexpr bool ROWSTATS = true;
+  static constexpr bool STAGE_AFF = true;
   template <int BM, int BN, int NT>
   TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid, const float2* rs) const { run_rows<BM, BN, NT>(Ct, LDC, m0, n0, M, tid, rs); }
   template <int BM, int BN, int NT>
@@ -707,7 +710,7 @@ struct EpiHead {
       float v[8];
       ct_load8(Ct, LDC, row, col, v);
       {  // the head's projection itself: every mode below consumes v[j] = acc ws + bias (of the normalised row)
-        const RowAff ra = row_aff(rs[row], ctl.wscale);
+        const float2 ra = rs[row];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = aff(v[j], ra, ci[j], bi[j]);
       }
@@ -783,6 +786,7 @@ struct EpiStoreF32 {
   int act;
   EpiCtl ctl;
   static constexpr bool ROWSTATS = false;
+  static constexpr bool PREFETCH = false;
   struct Cols {
     float bi[8];
     // a (free) register use that makes the compiler wait for the loads HERE, once: left to the first use inside a row loop,
@@ -862,6 +866,8 @@ struct EpiResid {
   EpiCtl ctl;
   LnStats ln{};
   static constexpr bool ROWSTATS = true;
+  static constexpr bool STAGE_AFF = false;  // the kernel stages (mean, rstd): the residual is normalised itself, not a product of it
+  static constexpr bool PREFETCH = true;  // the register epilogue requests row tile mi + 1's residual piece ahead of row tile mi's stores
   static_assert(Op::PREC != 0, "the deferred LayerNorm serves the 16-bit modes (f32 keeps the reference's operation order)");
   static constexpr int LANE_CHUNK = 8;
   static constexpr bool TRANSPOSED = false;
@@ -893,6 +899,15 @@ struct EpiResid {
     static_assert(N == 8, "row pieces of 8 columns");
     float u[8];
     g_load8(x + (long)gr * d + gn, u);
+    finish_piece<true>(gr, gn, v, u, bi, ci, st, am);
+  }
+  template <int N>
+  TAMF_DEV void prefetch(int gr, int gn, float (&u)[N]) const {
+    static_assert(N == 8, "row pieces of 8 columns");
+    g_load8(x + (long)gr * d + gn, u);
+  }
+  template <int N>
+  TAMF_DEV void finish_pf(int gr, int gn, float (&v)[N], const float (&u)[N], const float (&bi)[N], const float (&ci)[N], float2 st, float& am) const {
     finish_piece<true>(gr, gn, v, u, bi, ci, st, am);
   }
   template <int BM, int BN, int NT>
@@ -1066,7 +1081,7 @@ TAMF_DEV void gemm_tile(const GemmArgs<Op>& ga, const Epi& epi, const int m0, co
   TAMF_ISSUE_ALL(rot, 0)
   // deferred LayerNorm: (mean, rstd) of the tile's rows, staged behind the staging buffers while the first K tile is in flight
   float2* const rstat = (float2*)(smem + SM::STATS_OFF);
-  if constexpr (Epi::ROWSTATS) ln_stage<NT>(epi.ln, m0, BM, M, rstat, tid);
+  if constexpr (Epi::ROWSTATS) ln_stage<NT, Epi::STAGE_AFF, (BM + NT / 4 - 1) / (NT / 4)>(epi.ln, epi.ctl.wscale, m0, BM, M, rstat, tid);
   __syncthreads();
   TAMF_TS(ts1);
 

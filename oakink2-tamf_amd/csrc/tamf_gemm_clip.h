@@ -101,10 +101,11 @@ struct ClipCfg {
   static constexpr int NSTAGE = (3 * STAGE <= 160 * 1024) ? 3 : 2;
   // + a lane-private scratch row tile per wave (16 bytes x NI per lane) for the rolled form of an epilogue with an activation
   static constexpr int SCRATCH_OFF = NSTAGE * STAGE, SCRATCH_WAVE = NI * 1024;
-  // + (mean, rstd) of the tile's rows for the epilogues that normalise (deferred LayerNorm, tamf_device.h): two slots - the X waves
-  // stage the next tile's rows while the Y waves may still be storing this one's
+  // + the row terms of the tile's rows for the epilogues that normalise (deferred LayerNorm, tamf_device.h): three slots, tile of round
+  // r in slot r % 3 - the X waves stage tile r + 1 when they have stored tile r - 1, while the Y waves may still be storing tile r - 1
+  // themselves (slot (r - 1) % 3) and tile r's slot is about to be read by both
   static constexpr int STATS_OFF = SCRATCH_OFF + 8 * SCRATCH_WAVE;
-  static constexpr int BYTES = STATS_OFF + 2 * MT * 8;
+  static constexpr int BYTES = STATS_OFF + 3 * MT * 8;
   static_assert(BYTES <= 160 * 1024, "LDS budget");
   // LDS-DMA pieces per K tile of loader wave nq: PIECES_HI for nq < PIECES_REM, else PIECES_HI - 1
   static constexpr int PIECES_HI = (NPIECE + 3) / 4, PIECES_REM = NPIECE % 4 == 0 ? 4 : NPIECE % 4;
@@ -352,6 +353,33 @@ TAMF_DEV void clip_store_rows_act(const Epi& epi, const f32x4 (&acc)[C::MSUB0][N
                                   const float (&bi)[C::NCHUNK][C::CHUNK], const float (&ci)[C::NCHUNK][C::CHUNK], const float2* rs,
                                   float& am) {
   constexpr int CH = C::CHUNK;
+  if constexpr (Epi::ROWSTATS && Epi::PREFETCH) {
+    // the epilogue reads a row piece of its own output buffer per row tile (EpiResid: the residual stream, in place).  Requested inside
+    // the row loop, each piece would wait behind the previous row tile's stores (vmcnt retires in order): one store round trip per
+    // row tile.  So row tile mi + 1's pieces are requested BEFORE row tile mi is stored - the wait for them then leaves those stores
+    // in flight (the compiler counts them: straight-line code).
+    static_assert(C::NCHUNK == 1, "one row piece per lane and row tile");
+    float u[2][CH];
+    {
+      const int r = row0 < Sp ? row0 : Sp - 1;
+      epi.template prefetch<CH>(m0 + r, gn, u[0]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MS; ++mi) {
+      const int r = row0 + mi * 16;
+      if (mi + 1 < MS) {
+        const int rn = r + 16 < Sp ? r + 16 : Sp - 1;
+        epi.template prefetch<CH>(m0 + rn, gn, u[(mi + 1) & 1]);
+      }
+      if (r < Sp) {
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = acc[mi][j / 4][j % 4];
+        epi.template finish_pf<CH>(m0 + r, gn, v, u[mi & 1], bi[0], ci[0], rs[r], am);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MS; ++mi) {
     const int r = row0 + mi * 16;
@@ -519,6 +547,22 @@ struct ClipStream {
   }
 };
 
+// Deferred LayerNorm: the row terms of the workgroup's first TWO tiles (slots 0 and 1), staged by ALL eight waves ahead of the first
+// barrier, while the first K tiles are in flight - most launches give a workgroup one or two tiles, and staging a tile at the boundary
+// in front of it waits behind the epilogue's stores
+template <class Op, class C, class Epi>
+TAMF_DEV void clip_stage_first(const ClipGemmArgs<Op>& ga, const Epi& epi, int ntn, float2* rstat, int tid) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int tr = clip_tile_of(ga.n_tiles, r);
+    if (tr >= 0) {
+      int base, rows;
+      clip_part(ga, tr / ntn, base, rows);
+      ln_stage<512, Epi::STAGE_AFF, (C::MT + 127) / 128>(epi.ln, epi.ctl.wscale, base, rows, base + rows, rstat + r * C::MT, tid);
+    }
+  }
+}
+
 template <class Op, int NSUB, int NI, int XSUB, class Epi>
 __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op> ga, const Epi epi) {
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
@@ -542,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int w_frag = (C::MT + wn0 + lr) * BKB;
   const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
   char* slot = smem + C::SCRATCH_OFF + wave * C::SCRATCH_WAVE + lane * 16;
-  float2* const rstat = (float2*)(smem + C::STATS_OFF);  // [2][MT] (mean, rstd) of the rows of the tile of round r: slot r & 1
+  float2* const rstat = (float2*)(smem + C::STATS_OFF);  // [3][MT] row terms of the tile of round r: slot r % 3
   static_assert(!(TR && Epi::ROWSTATS), "the transposed epilogue has no deferred-LayerNorm form");
 
   // The workgroup is persistent over its tiles (rounds of the grid) and treats their K tiles as ONE stream: interval j
@@ -570,11 +614,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     for (int mi = 0; mi < C::MSUBX; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (Epi::ROWSTATS) {  // (mean, rstd) of the first tile's rows, while its first K tiles are in flight
-      int base, rows;
-      clip_part(ga, clip_tile_of(ga.n_tiles, 0) / ntn, base, rows);
-      ln_stage<256>(epi.ln, base, rows, base + rows, rstat, tid);
-    }
+    if constexpr (Epi::ROWSTATS) clip_stage_first<Op, C, Epi>(ga, epi, ntn, rstat, tid);
     // K tile 0 has landed: everything but the LA - 1 requests behind it
     if constexpr (LA == 2) {
       if (nq < C::PIECES_REM) clip_wait_vm<C::PIECES_HI>(); else clip_wait_vm<C::PIECES_HI - 1>();
@@ -655,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           int base, rows;
           clip_part(ga, b, base, rows);
           if (!(TAMF_ABL(ga.abl) & 4))
-            clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round & 1) * C::MT, TAMF_ABL(ga.abl), slot);
+            clip_store_rows<C, NI, C::MSUBX>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round % 3) * C::MT, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBX; ++mi)
@@ -663,11 +703,17 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         kt = 0;
         t = clip_tile_of(ga.n_tiles, ++round);
-        if constexpr (Epi::ROWSTATS) {  // the next tile's row statistics into the other slot (Y may still be reading this tile's)
-          if (t >= 0) {
-            int base, rows;
-            clip_part(ga, t / ntn, base, rows);
-            ln_stage<256>(epi.ln, base, rows, base + rows, rstat + (round & 1) * C::MT, tid);
+        if constexpr (Epi::ROWSTATS) {
+          // tiles 0 and 1 were staged up front; entering tile `round` >= 1, tile round + 1 (if any) goes into slot (round + 1) % 3 = the
+          // slot of tile round - 2, which nobody reads any more (Y stored tile round - 2 before a barrier X passed a whole tile ago;
+          // Y may still be storing tile round - 1 from ITS slot)
+          if (round >= 1) {
+            const int tn = clip_tile_of(ga.n_tiles, round + 1);
+            if (tn >= 0) {
+              int base, rows;
+              clip_part(ga, tn / ntn, base, rows);
+              ln_stage<256, Epi::STAGE_AFF, (C::MT + 63) / 64>(epi.ln, epi.ctl.wscale, base, rows, base + rows, rstat + ((round + 1) % 3) * C::MT, tid);
+            }
           }
         }
       }
@@ -683,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     for (int mi = 0; mi < C::MSUBY; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (Epi::ROWSTATS) clip_stage_first<Op, C, Epi>(ga, epi, ntn, rstat, tid);
     clip_barrier_lds();  // K tile 0 has landed (X waited for it)
     int4 ywf[NI][2], yaf[C::MSUBY][2];
     clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
@@ -724,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           int base, rows;
           clip_part(ga, b, base, rows);
           if (!(TAMF_ABL(ga.abl) & 4))
-            clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round & 1) * C::MT, TAMF_ABL(ga.abl), slot);
+            clip_store_rows<C, NI, C::MSUBY>(epi, acc, wm0 + lr, rows, base, n0 + lane_col, bi, ci, rstat + (round % 3) * C::MT, TAMF_ABL(ga.abl), slot);
         }
 #pragma unroll
         for (int mi = 0; mi < C::MSUBY; ++mi)

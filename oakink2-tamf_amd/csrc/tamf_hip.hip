@@ -1982,6 +1982,26 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       const int d = N / 3;
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
       e = gemm128<Op>(ga, ep, st);
+    } else if (epi_kind >= 10 && epi_kind <= 12) {
+      // the deferred-LayerNorm forms (16-bit modes): 10 = FFN1 with the row terms, 11 = QKV with the row terms, 12 = residual GEMM
+      if constexpr (Op::PREC != 0) {
+        const LnStats ln{(const float2*)x, K / 32, 1.0f / (float)K, 1e-5f};  // (any finite numbers: x is M x N >= M x K / 16 floats)
+        if (epi_kind == 10) {
+          EpiBiasAct<Op, true> ep{vec, nullptr, 0, o, N, ACT_GELU, {}, vec + N, ln};
+          if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op, true>>::applies(M / 208, 208, N, K))
+            e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
+          else e = gemm128<Op>(ga, ep, st);
+        } else if (epi_kind == 11) {
+          const int d = N / 3;
+          EpiQKV<Op, true> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f, {}, vec + N, ln};
+          e = gemm128<Op>(ga, ep, st);
+        } else {
+          EpiResid<Op> ep{vec, vec + N, x, o, N, (float2*)o2, ACT_NONE, {}, LnStats{nullptr, N / 32, 1.0f / (float)N, 1e-5f}};
+          e = M % 208 == 0 ? launch_resid<Op>(ga, ep, M / 208, 208, st) : gemm128<Op>(ga, ep, st);
+        }
+      } else {
+        e = hipErrorInvalidValue;
+      }
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};
       if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op>>::applies(M / 208, 208, N, K)) {
