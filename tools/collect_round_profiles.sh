@@ -7,6 +7,8 @@
 # Pass the commit the tree was built from as TAMF_COMMIT=<sha> (the GPU box has no .git): it is stamped into hbm_traffic_*.json,
 # which bench.py reports as roofline.traffic_source.
 export TMPDIR=/tmp
+# (an unstamped or default-round run used to overwrite the previous round's evidence)
+if [ -z "$TAMF_ROUND" ] || [ -z "$TAMF_COMMIT" ]; then echo "collect_round_profiles.sh: set TAMF_ROUND (e.g. r05) and TAMF_COMMIT (the sha the tree was built from)" >&2; exit 2; fi
 out=gpurun_out/prof; rm -rf $out; mkdir -p $out
 for dt in ${1:-f16x3 f32 bf16 bf16x3}; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$dt -o r -- python3 bench.py --no-power --steps 1 --warmup 0 --ddpm-steps 100 --no-cpu-baseline --also "" --fp32-loops 0 --dtype $dt > $out/ks_$dt.log 2>&1
@@ -29,17 +31,25 @@ PY
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.getcwd())
 out, dt = sys.argv[1:3]
-CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"), ("EpiStoreF32", "gemm_ffn2"),  # (clip_gemm_kernel<..., EpiBiasAct / EpiStoreF32> carry the same epilogue names)
-           ("residual_ln_kernel", "ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
+CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"),
+           ("EpiResid", "pair:gemm_outproj:gemm_ffn2"),     # 16-bit modes (deferred LayerNorm): out-proj and FFN2 alternate, layer by layer
+           ("EpiStoreF32", "pair:gemm_outproj:gemm_ffn2"),  # f32: the same two GEMMs in front of their LayerNorm kernels
+           ("residual_ln_kernel", "pair:outproj_residual_ln:ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
 SPLIT = dt in ("bf16x3", "f16x3")  # split modes: every EpiLN launch is the out-proj; the others alternate out-proj / FFN2 per layer
 def per_launch(ctr):
     f = glob.glob(f"{out}/pmc_{dt}_{ctr}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
     ln_seen = {}
+    pair_seen = collections.defaultdict(dict)
     for r in rows:
         for pat, name in CLASSES:
             if pat in r["Kernel_Name"]:
+                if name.startswith("pair:"):
+                    seen = pair_seen[pat]
+                    if r["Dispatch_Id"] not in seen:
+                        seen[r["Dispatch_Id"]] = len(seen)
+                    name = name.split(":")[1 + seen[r["Dispatch_Id"]] % 2]
                 if name == "gemm_ln":
                     if r["Dispatch_Id"] not in ln_seen:
                         ln_seen[r["Dispatch_Id"]] = len(ln_seen)
@@ -61,7 +71,7 @@ PY
   python3 bench.py --no-power --steps 1 --warmup 1 --no-cpu-baseline --also "" --fp32-loops 0 --dtype $dt --profile-out $out/step_profile_$dt.json > $out/step_$dt.log 2>&1
 done
 # the traffic files of THIS tree go where bench.py looks for them (roofline.traffic / traffic_stale) before the bench lines are taken
-if [ -d profiles/${TAMF_ROUND:-r04} ]; then cp $out/hbm_traffic_*.json profiles/${TAMF_ROUND:-r04}/; fi
+mkdir -p profiles/$TAMF_ROUND && cp $out/hbm_traffic_*.json profiles/$TAMF_ROUND/
 timeout 900 python3 bench.py > $out/bench_default.log 2>&1
 tail -n 1 $out/bench_default.log | cut -c1-600
 # the clip length the reference's dataset emits (T = 160) and the two 8-GPU presets' per-GPU shards, one line each
