@@ -46,8 +46,12 @@ typedef enum tamf_status {
 
 /* bits of tamf_get_status_flags */
 typedef enum tamf_status_flag {
-  TAMF_STATUS_F16_RANGE = 1 /* f16x3 only: an activation beyond +-65504 (or +-inf) was stored as a split-fp16 operand since the
-                               last clear; results computed since then may differ from the reference's fp32 arithmetic */
+  TAMF_STATUS_F16_RANGE = 1, /* f16x3 only: an activation beyond +-65504 (or +-inf) was stored as a split-fp16 operand since the
+                                last clear; results computed since then may differ from the reference's fp32 arithmetic */
+  TAMF_STATUS_F16_WEIGHT_RANGE = 2 /* f16x3 only, set by tamf_finalize_weights and never cleared: more than 1 % of the non-zero weights
+                                      of some tensor are below 2^-17.5 of that tensor's largest magnitude (one power-of-two scale per
+                                      tensor: an outlier dominates it) and are stored with fewer than 22 significand bits;
+                                      tamf_last_error names the tensor after the call.  The Python modules fall back to f32. */
 } tamf_status_flag;
 
 /* arithmetic mode of the MFMA contractions (everything else - residual stream, LayerNorm, softmax,

@@ -443,8 +443,9 @@ TAMF_DEV float ln_row_sum512(const float (&v)[8]) {
 // 64 x d LayerNorm-fused tile ran at 7 - 20 % of peak, the separate LayerNorm kernels moved 109 MB each).  So the normalised value is
 // never materialised: the residual stream holds the UN-normalised sums u (fp32 + operand), the GEMM that produces a row block also
 // leaves partial statistics of it, and every consumer applies the normalisation itself -
-//   a GEMM over LN(u):     LN(u) . W^T = rstd[m] (u . (gamma o W)^T - mean[m] c1[n]) + c2[n],   c1 = (gamma o W) 1,  c2 = W beta + b
-//                          (gamma folded into the weights, c1 / c2 computed at tamf_finalize_weights; Epi*::ln);
+//   a GEMM over LN(u):     LN(u) . W^T = rstd[m] (u . W''^T) + c2[n],   W'' = W diag(gamma) (I - 1 1^T / d),  c2 = W beta + b
+//                          (gain AND centring folded into the weights at tamf_finalize_weights - the rows of W'' sum to zero, so the
+//                          row mean drops out of the product by itself; Epi*::ln);
 //   the residual add:      u_next[m][n] = ((u[m][n] - mean[m]) rstd[m] gamma[n] + beta[n]) + (acc + bias)           (EpiResid).
 // Statistics: the producer's epilogue writes, per row and per block of 32 columns, (S_b, Q_b) = (sum, sum of squares about the
 // block's own mean); a consumer stages (mean, rstd) of its tile's rows in LDS before its K loop (ln_stage).  Both are fixed trees -
@@ -489,8 +490,8 @@ TAMF_DEV float2 ln_block_partial(const float (&v)[8]) {
 // (mean, rstd) of rows [r0, r0 + rows) into out[0 .. rows) (LDS), by NT threads, 4 lanes (a quad) per row: lane q of the quad takes the
 // blocks q NB/4 .. (q + 1) NB/4 - 1 in order, the quad combines as (q0 + q1) + (q2 + q3).  mean = S / d;
 // M2 = sum_b (Q_b + 32 (S_b / 32 - mean)^2); rstd = 1 / sqrt(M2 / d + eps).  Rows past row_limit are clamped (their value is never used).
-// AFF: what a GEMM behind the LayerNorm needs per row is staged instead - (ra, rb) = (rstd ws, -(rstd mean)), so that its epilogue
-// is out = fma(acc, ra, fma(rb, c1[n], c2[n])) (tamf_gemm.h; ws = the power-of-two weight scale of the launch).
+// AFF: what a GEMM behind the LayerNorm needs per row is staged instead - its factor ra = rstd ws (in .x), so that its epilogue
+// is out = fma(acc, ra, c2[n]) (tamf_gemm.h: the centring is folded into the weight; ws = the power-of-two weight scale of the launch).
 // MAXP = passes of NT / 4 rows that cover the tile: the partials of ALL passes are requested before the first is combined (one
 // global-load latency per tile, not one per pass - the first form of this function cost the FFN1 launch 6 us).
 struct LnRaw {
@@ -505,7 +506,7 @@ TAMF_DEV void ln_stage(const LnStats& s, float ws, int r0, int rows, int row_lim
   if (!s.part) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p)
-      if (q == 0 && rq + p * RPP < rows) out[rq + p * RPP] = AFF ? make_float2(ws, -0.0f) : make_float2(0.f, 1.f);
+      if (q == 0 && rq + p * RPP < rows) out[rq + p * RPP] = AFF ? make_float2(ws, 0.f) : make_float2(0.f, 1.f);
     return;
   }
   const int nbq = s.NB >> 2;
@@ -549,7 +550,7 @@ TAMF_DEV void ln_stage(const LnStats& s, float ws, int r0, int rows, int row_lim
     m2 = ln_sum4<false>(m2);
     const float rstd = 1.0f / sqrtf(m2 * s.inv_d + s.eps);
     const int r = rq + p * RPP;
-    if (q == 0 && r < rows) out[r] = AFF ? make_float2(rstd * ws, -(rstd * mean)) : make_float2(mean, rstd);
+    if (q == 0 && r < rows) out[r] = AFF ? make_float2(rstd * ws, 0.f) : make_float2(mean, rstd);
   }
 }
 

@@ -81,10 +81,13 @@ TAMF_DEV void settle(const float (&v)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) asm volatile("" ::"v"(v[j]));
 }
-// Deferred LayerNorm in front of a GEMM (tamf_device.h): out = rstd (acc ws - mean c1[n]) + c2[n] = fma(acc, ra, fma(rb, c1[n], c2[n])) with the row
-// terms ra = rstd ws, rb = -(rstd mean).  With (mean, rstd) = (0, 1) - no LayerNorm in front - it is fma(acc, ws, c2[n]) bit for bit.
-// The kernel stages (ra, rb) per row of the tile (ln_stage<.., true>): st.x = ra, st.y = rb.
-TAMF_DEV float aff(float acc, float2 st, float c1, float c2) { return fmaf(acc, st.x, fmaf(st.y, c1, c2)); }
+// Deferred LayerNorm in front of a GEMM (tamf_device.h).  LN(u) = rstd ((u - mean 1) o gamma) + beta, and the centring u - mean 1 = C u
+// with C = I - 1 1^T / d is linear, so it is folded into the weight together with the gain: W'' = W diag(gamma) C, i.e.
+// W''[n][k] = gamma[k] W[n][k] - (sum_j gamma[j] W[n][j]) / d (rows of zero sum, tamf_finalize_weights).  Then
+//   LN(u) . W^T = rstd[m] (u . W''^T)[m][n] + c2[n],   c2 = W beta + b
+// and the epilogue is ONE fma with a per-row factor, out = fma(acc, ra, c2[n]), ra = rstd ws - the cost of the plain fma(acc, ws, bias).
+// With rstd = 1 - no LayerNorm in front - it IS fma(acc, ws, bias).  The kernel stages (ra, -) per row of the tile (ln_stage<.., true>).
+TAMF_DEV float aff(float acc, float2 st, float c2) { return fmaf(acc, st.x, c2); }
 
 TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
   gst16f(p, v[0], v[1], v[2], v[3]);
@@ -93,7 +96,8 @@ TAMF_DEV void g_store8(float* p, const float (&v)[8]) {
 
 // out = act(C + bias[n] + rowadd[m][n]) stored as an operand (FFN1+GELU, input_merge.0+SiLU, hoisted GEMMs)
 // LN = true: the A operand holds UN-normalised rows u and the LayerNorm in front of this GEMM is applied here (deferred LayerNorm):
-// bias = c2, c1 = column sums of the gamma-folded weight, ln = partial statistics of the rows (staged by the kernel: `rs`).
+// the weight is W diag(gamma) C (gain and centring folded in), bias = c2 = W beta + b, ln = partial statistics of the rows (staged by
+// the kernel: `rs`).
 template <class OutOp, bool LN = false>
 struct EpiBiasAct {
   const float* bias;    // [N] or null
@@ -103,26 +107,20 @@ struct EpiBiasAct {
   int ldo;
   int act;
   EpiCtl ctl;
-  const float* c1 = nullptr;  // [N] (LN)
   LnStats ln{};
   static constexpr bool ROWSTATS = LN;
-  static constexpr bool STAGE_AFF = true;  // the kernel stages (ra, rb) per row
+  static constexpr bool STAGE_AFF = true;  // the kernel stages the row factor ra = rstd ws
   static constexpr bool PREFETCH = false;
   // Column constants of a thread (its 8 columns are the same for all its rows): loaded once per tile, ahead of the row
   // loops - a global load inside the row loop serialises the loop on L2 latency, and a load issued after stores waits for
   // them (vmcnt is in order), which is why the slab-wise epilogue of tamf_gemm_clip.h fetches these before its first slab
   struct Cols {
     float bi[8];
-    float ci[LN ? 8 : 1];
     // a (free) register use that makes the compiler wait for the loads HERE, once: left to the first use inside a row loop,
     // its s_waitcnt vmcnt(0) is repeated every iteration and then waits for the previous iteration's stores
     TAMF_DEV void settle() const {
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(bi[j]));
-      if constexpr (LN) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ci[j]));
-      }
     }
   };
   template <int BN, int NT>
@@ -132,7 +130,6 @@ struct EpiBiasAct {
 #pragma unroll
     for (int j = 0; j < 8; ++j) c.bi[j] = 0.f;
     if (bias) g_load8(bias + n0 + (tid % VPR) * 8, c.bi);
-    if constexpr (LN) g_load8(c1 + n0 + (tid % VPR) * 8, c.ci);
     return c;
   }
   template <int BM, int BN, int NT>
@@ -152,7 +149,7 @@ struct EpiBiasAct {
         if (gr >= M) break;
         float v[8];
         ct_load8(Ct, LDC, row, col, v);
-        finish_ln<8>(act, gr, gn, v, cc.bi, cc.ci, rs[row], am);
+        finish_ln<8>(act, gr, gn, v, cc.bi, cc.bi, rs[row], am);
       }
     } else if (rowadd) {
       // the row terms of all of this thread's rows are requested (and waited for) before the first store: a load issued behind
@@ -207,17 +204,19 @@ struct EpiBiasAct {
     }
     act_store<N>(a, gr, gn, v, am);
   }
-  // the same with the deferred LayerNorm of the row (st = its (mean, rstd)): bi = c2, ci = c1
+  // the same with the deferred LayerNorm of the row (st.x = its factor ra): bi = c2 (the second constant set of the register epilogue is
+  // EpiResid's; unused here)
   template <int N>
-  TAMF_DEV void finish_ln(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&ci)[N], float2 st, float& am) const {
+  TAMF_DEV void finish_ln(int a, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&)[N], float2 st, float& am) const {
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = aff(v[j], st, ci[j], bi[j]);
+    for (int j = 0; j < N; ++j) v[j] = aff(v[j], st, bi[j]);
     act_store<N>(a, gr, gn, v, am);
   }
   template <int N>
   TAMF_DEV void lane_cols_ln(int gn, float (&bi)[N], float (&ci)[N]) const {
     g_loadn<N>(bias + gn, bi);
-    g_loadn<N>(c1 + gn, ci);
+#pragma unroll
+    for (int j = 0; j < N; ++j) ci[j] = 0.f;
   }
   // activation + operand store (the sum is complete)
   template <int N>
@@ -304,7 +303,7 @@ struct EpiVt {
 
 // in_proj: columns [0,d) = Q (scaled by qscale), [d,2d) = K -> row-major [M][2d]; [2d,3d) = V -> transposed
 // per (clip, head): Vt[((b*H + h)*hd + e)][s], keys contiguous (what the P.V MFMA wants as its K axis).
-// LN = true: deferred LayerNorm of the input rows (see EpiBiasAct): bias = c2, c1 = column sums of the gamma-folded in_proj weight.
+// LN = true: deferred LayerNorm of the input rows (see EpiBiasAct): the weight is in_proj diag(gamma) C, bias = c2.
 template <class Op, bool LN = false>
 struct EpiQKV {
   const float* bias;  // [3d]
@@ -313,13 +312,12 @@ struct EpiQKV {
   int d, H, hd, Sp, Skp;
   float qscale;
   EpiCtl ctl;
-  const float* c1 = nullptr;  // [3d] (LN)
   LnStats ln{};
   static constexpr bool ROWSTATS = LN;
   static constexpr bool STAGE_AFF = true;
   // C element of tile row `row` -> projected value: acc ws + bias, or the row's deferred LayerNorm applied on the way
-  TAMF_DEV float proj(float acc, int row, float bb, float cc, float ws, const float2* rs) const {
-    if constexpr (LN) return aff(acc, rs[row], cc, bb);
+  TAMF_DEV float proj(float acc, int row, float bb, float ws, const float2* rs) const {
+    if constexpr (LN) return aff(acc, rs[row], bb);
     else return fmaf(acc, ws, bb);
   }
   template <int BM, int BN, int NT>
@@ -330,11 +328,9 @@ struct EpiQKV {
       static_assert(NT % VPR == 0, "column group must be fixed per thread");
       const float sc = (n0 < d) ? qscale : 1.0f;
       const int col = (tid % VPR) * 8, gn = n0 + col;
-      float b[8], c[8];
+      float b[8];
       g_load8(bias + gn, b);
-      if constexpr (LN) g_load8(c1 + gn, c);
       settle(b);
-      if constexpr (LN) settle(c);
       float am = 0.f;
       // rows in batches of 4: the C-tile reads of a batch are requested together (one LDS latency per batch instead of one per row:
       // left to itself the loop is read - wait - convert - store, row by row)
@@ -350,7 +346,7 @@ struct EpiQKV {
             if constexpr (LN) {
               const float2 ra = rs[tid / VPR + (r0 + i) * RSTEP];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[i][j] = aff(v[i][j], ra, c[j], b[j]) * sc;
+              for (int j = 0; j < 8; ++j) v[i][j] = aff(v[i][j], ra, b[j]) * sc;
             } else {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[i][j] = fmaf(v[i][j], ws, b[j]) * sc;
@@ -369,10 +365,10 @@ struct EpiQKV {
         const int eg = n0 - 2 * d + col;
         const int h = eg / hd, e = eg % hd;
         const int b = gr0 / Sp, s0 = gr0 % Sp;
-        const float bb = bias[n0 + col], cc = LN ? c1[n0 + col] : 0.f;
+        const float bb = bias[n0 + col];
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = proj(Ct[(rg * 8 + j) * LDC + col], rg * 8 + j, bb, cc, ws, rs);
+        for (int j = 0; j < 8; ++j) v[j] = proj(Ct[(rg * 8 + j) * LDC + col], rg * 8 + j, bb, ws, rs);
         Op::template store<8>(vt, ((long)(b * H + h) * hd + e) * Skp + s0, v);
       }
     } else {
@@ -397,15 +393,13 @@ struct EpiQKV {
         const int plane_off = (Op::SPLIT && piece >= 4) ? 64 : 0;
         const int ng = (M - m0 < BM ? M - m0 : BM) / 16;  // row groups of this tile that exist (M is a multiple of Sp)
         constexpr int NGRP = BN / FPW, NFG = (NGRP + NT / 64 - 1) / (NT / 64);  // feature groups of the tile / per wave
-        float bbs[NFG], ccs[NFG];
+        float bbs[NFG];
 #pragma unroll
         for (int i = 0; i < NFG; ++i) {
           const int fg = wv + i * (NT / 64);
           bbs[i] = bias[n0 + (fg < NGRP ? fg : 0) * FPW + f_lo];
-          ccs[i] = LN ? c1[n0 + (fg < NGRP ? fg : 0) * FPW + f_lo] : 0.f;
         }
         settle(bbs);
-        settle(ccs);
 #pragma unroll
         for (int i = 0; i < NFG; ++i) {
           const int fg = wv + i * (NT / 64);
@@ -413,7 +407,7 @@ struct EpiQKV {
           const int col = fg * FPW + f_lo;
           const int eg = n0 - 2 * d + col;
           const int h = eg / hd, e = eg % hd;
-          const float bb = bbs[i], cc = ccs[i];
+          const float bb = bbs[i];
           for (int r16 = 0; r16 < ng;) {
             const int gr = m0 + r16 * 16;
             const int b = gr / Sp, k16 = (gr % Sp) / 16;  // clip and 16-key group
@@ -422,10 +416,10 @@ struct EpiQKV {
             char* pp = (char*)vt + Op::byte_off(row_idx) + plane_off + q * 16;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(r16 * 16 + 4 * q + j) * LDC + col], r16 * 16 + 4 * q + j, bb, cc, ws, rs);
+            for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(r16 * 16 + 4 * q + j) * LDC + col], r16 * 16 + 4 * q + j, bb, ws, rs);
             if (pair) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 + j] = proj(Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col], r16 * 16 + 16 + 4 * q + j, bb, cc, ws, rs);
+              for (int j = 0; j < 4; ++j) v[4 + j] = proj(Ct[(r16 * 16 + 16 + 4 * q + j) * LDC + col], r16 * 16 + 16 + 4 * q + j, bb, ws, rs);
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[4 + j] = 0.f;
@@ -461,10 +455,10 @@ struct EpiQKV {
           const int eg = n0 - 2 * d + col;
           const int h = eg / hd, e = eg % hd;
           const int b = gr0 / Sp, s0 = gr0 % Sp;
-          const float bb = bias[n0 + col], cc = LN ? c1[n0 + col] : 0.f;
+          const float bb = bias[n0 + col];
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(row0 + j) * LDC + col], row0 + j, bb, cc, ws, rs);
+          for (int j = 0; j < 4; ++j) v[j] = proj(Ct[(row0 + j) * LDC + col], row0 + j, bb, ws, rs);
           Op::template store_rc<4>(vt, ((long)(b * H + h) * hd + e) * Skp + vt_key_pos<Op>(s0), v, am);
         }
       }
@@ -683,10 +677,8 @@ struct EpiHead {
   // same-address atomics from 8 XCDs).
   int t_off;
   EpiCtl ctl;
-  // The last LayerNorm of the encoder, deferred into this GEMM (tamf_device.h): bias = c2, c1 = column sums of the gamma-folded head
-  // weight (XN floats; zeros when ln.part is null - f32, whose rows arrive normalised: (mean, rstd) = (0, 1) then gives
-  // fma(acc, ws, bias) bit for bit)
-  const float* ln_c1 = nullptr;
+  // The last LayerNorm of the encoder, deferred into this GEMM (tamf_device.h): the weight is W_f diag(gamma) C, bias = c2; ln.part is
+  // null in f32, whose rows arrive normalised - the row factor is then ws and the projection is fma(acc, ws, bias) bit for bit
   LnStats ln{};
   static constexpr bool ROWSTATS = true;
   static constexpr bool STAGE_AFF = true;
@@ -697,9 +689,8 @@ struct EpiHead {
     constexpr int VPR = BN / 8, RSTEP = NT / VPR;
     static_assert(NT % VPR == 0, "column group must be fixed per thread");
     const int col = (tid % VPR) * 8, gn = n0 + col;
-    float bi[8], ci[8];
+    float bi[8];
     g_load8(bias + gn, bi);
-    g_load8(ln_c1 + gn, ci);
     float am = 0.f;
     for (int row = tid / VPR; row < BM; row += RSTEP) {
       const int gr = m0 + row;
@@ -712,7 +703,7 @@ struct EpiHead {
       {  // the head's projection itself: every mode below consumes v[j] = acc ws + bias (of the normalised row)
         const float2 ra = rs[row];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = aff(v[j], ra, ci[j], bi[j]);
+        for (int j = 0; j < 8; ++j) v[j] = aff(v[j], ra, bi[j]);
       }
       if (mode == HEAD_X0) {
 #pragma unroll

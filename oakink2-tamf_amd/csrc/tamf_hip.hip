@@ -47,9 +47,9 @@ struct OperandBuf {
 
 struct LayerW {
   OperandBuf Win, Wout, W1, W2;
-  // deferred LayerNorm (16-bit modes; tamf_device.h): Win / W1 hold gamma-folded weights, the consumers take (c1, c2) in place of the
-  // bias, the residual adds take (gamma, beta + bias) of the LayerNorm their residual passes through
-  float *c1_in = nullptr, *c2_in = nullptr, *c1_ff = nullptr, *c2_ff = nullptr;
+  // deferred LayerNorm (16-bit modes; tamf_device.h): Win / W1 hold W diag(gamma) (I - 1 1^T / d), the consumers take c2 = W beta + b
+  // in place of the bias, the residual adds take (gamma, beta + bias) of the LayerNorm their residual passes through
+  float *c2_in = nullptr, *c2_ff = nullptr;
   float *g_att = nullptr, *bb_att = nullptr, *g_ffn = nullptr, *bb_ffn = nullptr;
   float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
@@ -123,10 +123,11 @@ struct tamf_ctx {
   unsigned* status = nullptr;  // this context's sticky status word (tamf_device.h): written by its kernels only
   unsigned char* side_dev = nullptr;
   int* objnum_dev = nullptr;  // per-clip object counts of tamf_set_cond_ragged
+  unsigned host_status = 0;  // status bits raised on the host (TAMF_STATUS_F16_WEIGHT_RANGE at tamf_finalize_weights); never cleared
+  std::string weight_note;   // ... and which tensor raised it
   // deferred LayerNorm: partial row statistics of the residual stream after the attention / feed-forward sublayer, [Mmax][d / 32]
   bool defer_ln = false;
   float2 *stat_att = nullptr, *stat_ffn = nullptr;
-  float *c1_head = nullptr, *zeros_xn = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
@@ -213,12 +214,8 @@ static inline float h_bf2f(uint16_t h) {
 
 // upload host fp32 [N][K] as an operand matrix [N][ldk] in precision `prec` (cols >= K zero; ldk % 32 == 0).
 // bf16x3 rows are 128-byte groups of 32 elements: [hi: 32 bf16 | lo: 32 bf16] (tamf_device.h "Operand traits").
-// rowsum (optional): per output row, the sum over K of the values AS STORED (after rounding to the operand format) - the c1 vector of
-// a GEMM behind a deferred LayerNorm must cancel the mean against exactly what the MFMAs multiply
-static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what,
-                          std::vector<double>* rowsum = nullptr) {
+static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K, int ldk, OperandBuf* out, const char* what) {
   const size_t n = (size_t)N * ldk;
-  if (rowsum) rowsum->assign(N, 0.0);
   if (ldk % 32) return fail(ctx, TAMF_ERR_INVALID, "operand leading dimension must be a multiple of 32");
   int wexp = 0;  // f16x3: the tensor is stored as w * 2^wexp
   out->inv_scale = 1.0f;
@@ -243,22 +240,31 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
     wexp = 0;
 #endif
     out->inv_scale = std::ldexp(1.0f, -wexp);
+    // One power of two per tensor: a weight smaller than 2^-17.5 of the tensor's maximum has an fp16-SUBNORMAL lo part again (fewer than
+    // 22 significand bits).  Ordinary tensors are nowhere near (max / typical ~ 2^3 .. 2^7); one huge outlier over ordinary weights is
+    // (a single 7e4 among 0.04s leaves the others ~18 bits).  Reported, not refused: a status bit + the tensor's name.
+    size_t small = 0, nonzero = 0;
+    for (size_t i = 0; i < (size_t)N * K; ++i)
+      if (w[i] != 0.f) {
+        ++nonzero;
+        if (std::fabs(std::ldexp(w[i], wexp)) < 0.125f) ++small;
+      }
+    if (nonzero && small * 100 > nonzero) {
+      ctx->host_status |= TAMF_STATUS_F16_WEIGHT_RANGE;
+      if (ctx->weight_note.empty())
+        ctx->weight_note = std::string("f16x3: ") + std::to_string(small * 100 / nonzero) + " % of the non-zero weights of " + what +
+                           " are below 2^-17.5 of the tensor's largest magnitude: stored with fewer than 22 significand bits (an outlier dominates the per-tensor scale)";
+    }
   }
   if (prec == TAMF_PREC_F32) {
     std::vector<float> h(n, 0.f);
     for (int r = 0; r < N; ++r) memcpy(&h[(size_t)r * ldk], &w[(size_t)r * K], (size_t)K * 4);
-    if (rowsum)
-      for (int r = 0; r < N; ++r)
-        for (int k = 0; k < K; ++k) (*rowsum)[r] += w[(size_t)r * K + k];
     return dev_upload(ctx, (float**)&out->p, h.data(), n);
   }
   if (prec == TAMF_PREC_BF16) {
     std::vector<uint16_t> h(n, 0);
     for (int r = 0; r < N; ++r)
-      for (int k = 0; k < K; ++k) {
-        h[(size_t)r * ldk + k] = h_f2bf(w[(size_t)r * K + k]);
-        if (rowsum) (*rowsum)[r] += h_bf2f(h[(size_t)r * ldk + k]);
-      }
+      for (int k = 0; k < K; ++k) h[(size_t)r * ldk + k] = h_f2bf(w[(size_t)r * K + k]);
     return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n);
   }
   std::vector<uint16_t> h(n * 2, 0);
@@ -272,12 +278,10 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
         const _Float16 hi = (_Float16)vs, lo = (_Float16)(vs - (float)hi);
         memcpy(&h[o], &hi, 2);
         memcpy(&h[o + 32], &lo, 2);
-        if (rowsum) (*rowsum)[r] += std::ldexp((double)(float)hi + (double)(float)lo, -wexp);
       } else {
         const uint16_t hi = h_f2bf(v);
         h[o] = hi;
         h[o + 32] = h_f2bf(v - h_bf2f(hi));
-        if (rowsum) (*rowsum)[r] += (double)h_bf2f(h[o]) + (double)h_bf2f(h[o + 32]);
       }
     }
   return dev_upload(ctx, (uint16_t**)&out->p, h.data(), n * 2);
@@ -945,34 +949,33 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     const std::string p = "seqTransEncoder.layers." + std::to_string(l);
     LayerW& w = ctx->layers[l];
     if (ctx->defer_ln) {
-      // Deferred LayerNorm: fold the gain of the LayerNorm in front of a GEMM into its weight (W' = W diag(gamma)), c1 = W' 1 over the
-      // values as stored, c2 = W beta + bias (fp64); the residual adds take gamma and beta + bias of the LayerNorm their residual input
-      // passes through.  Layer 0's attention block reads the encoder input itself: identity (gamma 1, beta 0).
+      // Deferred LayerNorm: fold the gain AND the centring of the LayerNorm in front of a GEMM into its weight, W'' = W diag(gamma) (I - 1 1^T / d)
+      // (fp64: every row of W diag(gamma) minus its own mean), c2 = W beta + bias; the residual adds take gamma and beta + bias of the
+      // LayerNorm their residual input passes through.  Layer 0's attention block reads the encoder input itself: the plain weight.
       const std::string pp = "seqTransEncoder.layers." + std::to_string(l - 1);
       const float* g_in = l ? R(pp + ".norm2.weight") : nullptr;   // LayerNorm in front of this layer's attention block
       const float* be_in = l ? R(pp + ".norm2.bias") : nullptr;
       const float* g1 = R(p + ".norm1.weight");                    // ... in front of its feed-forward block
       const float* be1 = R(p + ".norm1.bias");
-      auto fold = [&](const float* W, const float* bias, int N, const float* g, const float* be, OperandBuf* ob, float** c1, float** c2,
+      auto fold = [&](const float* W, const float* bias, int N, const float* g, const float* be, OperandBuf* ob, float** c2,
                       const std::string& what) -> int {
-        std::vector<float> wf((size_t)N * d), v1(N), v2(N);
-        std::vector<double> rs;
+        std::vector<float> wf((size_t)N * d), v2(N);
         for (int n = 0; n < N; ++n) {
-          double acc = bias[n];
+          double acc = bias[n], rowsum = 0.0;
           for (int k = 0; k < d; ++k) {
-            wf[(size_t)n * d + k] = g ? W[(size_t)n * d + k] * g[k] : W[(size_t)n * d + k];
+            if (g) rowsum += (double)W[(size_t)n * d + k] * g[k];
             if (be) acc += (double)W[(size_t)n * d + k] * be[k];
           }
+          const double shift = g ? rowsum / d : 0.0;  // W'' = W diag(gamma) (I - 1 1^T / d): every row minus its own mean
+          for (int k = 0; k < d; ++k) wf[(size_t)n * d + k] = g ? (float)((double)W[(size_t)n * d + k] * g[k] - shift) : W[(size_t)n * d + k];
           v2[n] = (float)acc;
         }
-        TRY(upload_operand(ctx, prec, wf.data(), N, d, d, ob, what.c_str(), &rs));
-        for (int n = 0; n < N; ++n) v1[n] = g ? (float)rs[n] : 0.f;  // (no LayerNorm in front: the mean term is zero anyway)
-        TRY(dev_upload(ctx, c1, v1.data(), v1.size()));
+        TRY(upload_operand(ctx, prec, wf.data(), N, d, d, ob, what.c_str()));
         return dev_upload(ctx, c2, v2.data(), v2.size());
       };
-      TRY(fold(R(p + ".self_attn.in_proj_weight"), R(p + ".self_attn.in_proj_bias"), 3 * d, g_in, be_in, &w.Win, &w.c1_in, &w.c2_in,
+      TRY(fold(R(p + ".self_attn.in_proj_weight"), R(p + ".self_attn.in_proj_bias"), 3 * d, g_in, be_in, &w.Win, &w.c2_in,
                p + ".self_attn.in_proj_weight"));
-      TRY(fold(R(p + ".linear1.weight"), R(p + ".linear1.bias"), ff, g1, be1, &w.W1, &w.c1_ff, &w.c2_ff, p + ".linear1.weight"));
+      TRY(fold(R(p + ".linear1.weight"), R(p + ".linear1.bias"), ff, g1, be1, &w.W1, &w.c2_ff, p + ".linear1.weight"));
       std::vector<float> ga(d), bb(d);
       for (int n = 0; n < d; ++n) {
         ga[n] = g_in ? g_in[n] : 1.0f;
@@ -1045,27 +1048,24 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2, "input_merge.2.weight"));
   TRY(upload_f32(ctx, "input_merge.2.bias", &ctx->bm2));
   {
-    std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f), c1h(ctx->XN, 0.f);
+    std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f);
     memcpy(wf.data(), R("output_process.poseFinal.weight"), (size_t)F * d * 4);
     memcpy(bfp.data(), R("output_process.poseFinal.bias"), (size_t)F * 4);
-    std::vector<double> rs;
-    if (ctx->defer_ln) {  // the encoder's last LayerNorm, deferred into the head: W_f diag(gamma), c1, c2 = W_f beta + b_f
+    if (ctx->defer_ln) {  // the encoder's last LayerNorm, deferred into the head: W_f diag(gamma) (I - 1 1^T / d), c2 = W_f beta + b_f
       const std::string pl = "seqTransEncoder.layers." + std::to_string(ctx->L - 1);
       const float *g = R(pl + ".norm2.weight"), *be = R(pl + ".norm2.bias");
       for (int n = 0; n < F; ++n) {
-        double acc = bfp[n];
+        double acc = bfp[n], rowsum = 0.0;
         for (int k = 0; k < d; ++k) {
           acc += (double)wf[(size_t)n * d + k] * be[k];
-          wf[(size_t)n * d + k] *= g[k];
+          rowsum += (double)wf[(size_t)n * d + k] * g[k];
         }
+        for (int k = 0; k < d; ++k) wf[(size_t)n * d + k] = (float)((double)wf[(size_t)n * d + k] * g[k] - rowsum / d);
         bfp[n] = (float)acc;
       }
     }
-    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf, "output_process.poseFinal.weight", &rs));
-    if (ctx->defer_ln)
-      for (int n = 0; n < F; ++n) c1h[n] = (float)rs[n];
+    TRY(upload_operand(ctx, prec, wf.data(), ctx->XN, d, d, &ctx->Wf, "output_process.poseFinal.weight"));
     TRY(dev_upload(ctx, &ctx->bf, bfp.data(), bfp.size()));
-    TRY(dev_upload(ctx, &ctx->c1_head, c1h.data(), c1h.size()));
   }
   TRY(upload_f32(ctx, "sequence_pos_encoder.pe", &ctx->pe));
   TRY(upload_f32(ctx, "hand_shape_process.shape_embed.weight", &ctx->Wshape));
@@ -1098,6 +1098,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   HIPCHK(ctx, hipStreamSynchronize(st));
   ctx->raw.clear();
   ctx->finalized = true;
+  if (!ctx->weight_note.empty()) ctx->err = ctx->weight_note;  // (readable through tamf_last_error after the successful call)
   return 0;
 }
 
@@ -1294,7 +1295,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         const LnStats ln_ff{ctx->stat_att, NB, inv_d, 1e-5f};               // ... in front of the feed-forward block
         {
           GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
-          EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, w.c1_in, ln_in};
+          EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, ln_in};
           HIPCHK(ctx, gemm128<Op>(ga, ep, st));
           mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
         }
@@ -1311,7 +1312,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         }
         {
           GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
-          EpiBiasAct<Op, true> ep{w.c2_ff, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}, w.c1_ff, ln_ff};
+          EpiBiasAct<Op, true> ep{w.c2_ff, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}, ln_ff};
           bool on_clip = false;
           if (!(g_sel & 8)) {
             TAMF_CLIP_NSUB(Sp, {
@@ -1496,7 +1497,6 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.n_steps = ctx->n_steps;
   h.lp = ctx->loop_params;
   h.ctl = EpiCtl{ctx->Wf.inv_scale, ctx->status};
-  h.ln_c1 = ctx->c1_head;  // (zeros in f32)
   h.ln = LnStats{ctx->defer_ln ? ctx->stat_ffn : nullptr, ctx->d / 32, 1.0f / (float)ctx->d, 1e-5f};
   return h;
 }
@@ -1638,7 +1638,7 @@ extern "C" int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t cle
   // this context's own word (per-context since round 4: another context on the device neither sees nor clears it)
   unsigned v = 0;
   HIPCHK(ctx, hipMemcpy(&v, ctx->status, sizeof(v), hipMemcpyDeviceToHost));
-  *flags = v;
+  *flags = v | ctx->host_status;  // (the host-side bits describe the loaded weights: they are not cleared)
   if (clear && v) HIPCHK(ctx, hipMemset(ctx->status, 0, sizeof(v)));
   return 0;
 }
@@ -1987,13 +1987,13 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       if constexpr (Op::PREC != 0) {
         const LnStats ln{(const float2*)x, K / 32, 1.0f / (float)K, 1e-5f};  // (any finite numbers: x is M x N >= M x K / 16 floats)
         if (epi_kind == 10) {
-          EpiBiasAct<Op, true> ep{vec, nullptr, 0, o, N, ACT_GELU, {}, vec + N, ln};
+          EpiBiasAct<Op, true> ep{vec, nullptr, 0, o, N, ACT_GELU, {}, ln};
           if (M % 208 == 0 && ClipLaunch<Op, 4, EpiBiasAct<Op, true>>::applies(M / 208, 208, N, K))
             e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>>::launch(nullptr, a, K, w, K, M / 208, 208, N, K, ep, st);
           else e = gemm128<Op>(ga, ep, st);
         } else if (epi_kind == 11) {
           const int d = N / 3;
-          EpiQKV<Op, true> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f, {}, vec + N, ln};
+          EpiQKV<Op, true> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f, {}, ln};
           e = gemm128<Op>(ga, ep, st);
         } else {
           EpiResid<Op> ep{vec, vec + N, x, o, N, (float2*)o2, ACT_NONE, {}, LnStats{nullptr, N / 32, 1.0f / (float)N, 1e-5f}};

@@ -23,6 +23,7 @@ class TamfRangeError(TamfError):
 
 
 STATUS_F16_RANGE = 1
+STATUS_F16_WEIGHT_RANGE = 2
 DEFAULT_PRECISION = "f16x3"  # fp32-equivalent at the stated 1e-5 tolerance (22 significand bits for values >= 2^-3 of fp16's normal range - weights
 # are pre-scaled into it - and an absolute 3e-8 operand error below |v| = 0.12 for activations), range-guarded; DESIGN.md section 2
 
@@ -184,9 +185,11 @@ class TamfContext:
             pass
 
     # -- weights ------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Mapping[str, torch.Tensor], max_timesteps: int = 5000):
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], max_timesteps: int = 5000, strict_weight_range: bool = False):
         """max_timesteps = rows of the timestep-embedding table; the default covers every t the reference's
-        `pe[timesteps]` lookup accepts (sequence_pos_encoder.pe has 5000 rows)."""
+        `pe[timesteps]` lookup accepts (sequence_pos_encoder.pe has 5000 rows).  strict_weight_range (f16x3): raise
+        TamfRangeError when the library reports STATUS_F16_WEIGHT_RANGE - a tensor whose per-tensor scale is dominated by an
+        outlier, so that its ordinary weights keep fewer than 22 significand bits (the modules then fall back to f32)."""
         L = lib()
         self.max_timesteps = int(max_timesteps)
         for name, t in sd.items():
@@ -197,6 +200,9 @@ class TamfContext:
             _check(L.tamf_load_weight(self._h, name.encode(), c_void_p(h.data_ptr()), shape, max(h.dim(), 1)), self._h)
         with torch.cuda.device(self.device):
             _check(L.tamf_finalize_weights(self._h, int(max_timesteps), c_void_p(_stream_ptr(self.device))), self._h)
+        if strict_weight_range and self.precision == "f16x3" and (self.status_flags(clear=False) & STATUS_F16_WEIGHT_RANGE):
+            note = L.tamf_last_error(self._h)
+            raise TamfRangeError(note.decode() if note else "f16x3: a weight tensor's dynamic range exceeds the split-fp16 format")
 
     def set_schedule(self, coef1: np.ndarray, coef2: np.ndarray, log_variance_clipped: np.ndarray):
         c1 = np.ascontiguousarray(coef1, dtype=np.float64)

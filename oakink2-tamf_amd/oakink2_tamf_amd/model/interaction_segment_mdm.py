@@ -138,7 +138,7 @@ class _HipDenoiserBase(nn.Module):
             while True:
                 ctx = TamfContext(self._arch, mb, mf, precision=self.active_precision, device=dev, kind=self.kind)
                 try:
-                    ctx.load_state_dict(self.state_dict(), max_timesteps=self._max_timesteps)
+                    ctx.load_state_dict(self.state_dict(), max_timesteps=self._max_timesteps, strict_weight_range=self.range_check != "off")
                     break
                 except TamfRangeError as e:  # a weight beyond the fp16 range
                     ctx.close()

@@ -268,7 +268,17 @@ def test_f16x3_weights_of_any_finite_magnitude_load_and_only_non_finite_ones_are
         ctx.load_state_dict(w)
         _set_cond(ctx, cond)
         out = ctx.denoise(x, t).cpu()
-        assert ctx.status_flags() == 0, tag
+        # round 5: one power of two per tensor - the 7e4 outlier leaves the ordinary weights of ITS tensor with fewer than 22
+        # significand bits; that is reported (a status bit set at tamf_finalize_weights, the tensor named), not refused
+        from oakink2_tamf_amd.hip_backend import STATUS_F16_WEIGHT_RANGE, lib
+
+        assert ctx.status_flags() == (STATUS_F16_WEIGHT_RANGE if tag == "huge" else 0), tag
+        if tag == "huge":
+            assert b"layers.1.linear2.weight" in lib().tamf_last_error(ctx._h)
+            ctx2 = TamfContext(_arch_dict(arch), 2, 16, precision="f16x3")
+            with pytest.raises(TamfRangeError, match="layers.1.linear2.weight"):
+                ctx2.load_state_dict(w, strict_weight_range=True)
+            ctx2.close()
         err = float((out - ref).abs().max()) / max(1.0, float(ref.abs().max()))
         assert err < 1e-5, (tag, err)
         ctx.close()
