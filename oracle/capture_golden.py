@@ -533,6 +533,14 @@ def capture_stress():
                  sd_fn=O.det_state_dict_stress, cond_fn=O.det_cond_stress)
 
 
+def capture_stress_dc():
+    """Round 5: (iii) the stress weights + LayerNorm biases of 2 +- 0.5 on every feature (a DC component in every LayerNorm output, i.e.
+    residual rows whose mean is several times their spread) - the input the HIP path's deferred LayerNorm is most exposed to."""
+    capture_forward("stress_dc_t160", O.ARCH_MDM_L, B=2, T=160, ts=[0, 500, 999], sd_fn=O.det_state_dict_stress_dc, cond_fn=O.det_cond_stress)
+    capture_loop("stress_dc_b2_t160_50", O.ARCH_MDM_L, B=2, T=160, steps=50, store_noise=False, dump_steps=[0, 24, 48, 49],
+                 sd_fn=O.det_state_dict_stress_dc, cond_fn=O.det_cond_stress)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -559,6 +567,7 @@ def main():
     capture_loop_arch_mdm_l_1000()
     capture_loop_arch_mdm_1000()
     capture_stress()
+    capture_stress_dc()
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()

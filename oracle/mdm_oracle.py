@@ -248,6 +248,19 @@ def det_state_dict_stress(arch: Arch, tag: str = "w0") -> Dict[str, torch.Tensor
     return sd
 
 
+def det_state_dict_stress_dc(arch: Arch, tag: str = "w0") -> Dict[str, torch.Tensor]:
+    """det_state_dict_stress + a DC component in every LayerNorm output: biases beta = 2 + U(-0.5, 0.5) for all features (round 5).
+    The residual rows u = x + sublayer(x) then carry a row mean of about 2 beside a spread of 0.2 - 5 (the gains): |mean| / sigma up to
+    ~10 - the case the deferred LayerNorm of the HIP path (the normalisation applied by the CONSUMER of u, the row mean cancelling inside
+    the product against zero-sum weight rows) is most exposed to.  Fixtures: forward_stress_dc_t160.npz, loop_stress_dc_b2_t160_50.npz."""
+    sd = det_state_dict_stress(arch, tag)
+    for name in list(sd):
+        if ".norm" in name and name.endswith(".bias"):
+            u = det.det_uniform(f"{tag}/stress-beta/{name}", tuple(sd[name].shape), 0.5)
+            sd[name] = torch.from_numpy((2.0 + u).astype(np.float32))
+    return sd
+
+
 def det_cond_stress(B: int, T: int, nobj: int = 2, tag: str = "c0", arch: Arch = ARCH_MDM) -> Dict[str, object]:
     """det_cond with the magnitudes of real conditioning: CLIP text features of norm 10, object trajectories as
     [translation in metres | rot6d of a unit rotation] (obj_input_dim = 9: dev_fn/transform/rotation.py rot6d = the first two

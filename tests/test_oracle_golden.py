@@ -168,7 +168,7 @@ def test_philox_normal_moments_and_shard_independence():
 
 
 # ---- stress fixtures (round 4): trained-like dynamic range at the dataset's clip length, captured from the reference ------------------
-STRESS = {"stress_cond": O.det_state_dict, "stress_weights": O.det_state_dict_stress}
+STRESS = {"stress_cond": O.det_state_dict, "stress_weights": O.det_state_dict_stress, "stress_dc": O.det_state_dict_stress_dc}
 
 
 @pytest.mark.parametrize("kind", list(STRESS))
