@@ -268,9 +268,11 @@ def test_forward_clip_tiles_at_their_largest_padding(prec, B, T):
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
 @pytest.mark.parametrize("B,arch_name", [(64, "ARCH_MDM_L"), (32, "ARCH_MDM_L"), (64, "ARCH_MDM")])
 def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name):
-    """Every clip length from T = 139 to 204 (Sp = 144 .. 216: below, inside and above the 176- / 208-row clip tiles and their row
-    parts): the default kernels against the 128 x 128 / LayerNorm-fused tiles (selection 1: no clip tiles at all) - the same bits -
-    and finite.  (T = 172 .. 187 and 140 .. 155 used to run the f32 V^T clip tile past the V^T rows: vt_row_keys, csrc/tamf_hip.hip.)"""
+    """27 clip lengths between T = 139 and 204 (every fourth one plus the edges of the tile families; Sp = 144 .. 216: below, inside and
+    above the 176- / 208-row clip tiles and their row parts): the default kernels against the 128 x 128 tiles (selection 1: no clip
+    tiles at all) - the same bits - and finite.  (T = 172 .. 187 and 140 .. 155 used to run the f32 V^T clip tile past the V^T rows:
+    vt_row_keys, csrc/tamf_hip.hip.  A comparison of kernels with kernels cannot see a store that lands in a neighbouring live buffer;
+    EVERY length 1 .. 224 is walked by tests/test_hip_guardbands.py with guard bands around every allocation.)"""
     from oracle import mdm_oracle as O
     from oakink2_tamf_amd.hip_backend import lib
 
