@@ -109,6 +109,11 @@ TAMF_DEV float erf_as(float x) {
 //  instructions fewer per element and 3.3e-7 instead of 4.7e-7 max abs error on paper, but the FFN1 launch got SLOWER, 81.2 -> 84.9 us
 //  (f16x3, tools/kbench.py, two builds alternating on one box): the epilogue's time is not its instruction count)
 TAMF_DEV float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// (measured and dropped, round 5: the f32 mode's GELU through erfc(|z|) = t exp(-z^2 + P(t)) (Numerical Recipes' erfcc fit; ~20 VALU
+//  instructions per element against ~75 of libm's erff, the same 4e-7 max abs error in fp32) - the f32 FFN1 launch did not move,
+//  221.3 -> 222.4 us (profiles/r05/ab_f32_deferred_c16.txt): again, the epilogue's time is not its instruction count.  And its
+//  `2 - t * e` contracted to an fma in one tile form and not in the other: the batch-invariance test caught it - arithmetic shared
+//  by two kernel forms must leave the compiler no choice, hence the explicit fmaf / __fmul_rn / contract(off) everywhere.)
 
 // Per-loop inputs of the fused DDPM update.  They live in device memory and are read by the kernel, so the captured graph
 // does not depend on them: a new seed / clip range / noise tensor replays the same executable graph.
@@ -460,8 +465,10 @@ struct LnStats {
 
 // (S, Q) of 32 consecutive columns of one row, held as 8 consecutive values in each of 4 lanes: the lanes of a quad (LDS-walking
 // epilogues: GROUPS = false) or the 4 lane groups l, l ^ 16, l ^ 32, l ^ 48 (register epilogue of the clip tiles: GROUPS = true).
-// Every one of the 4 lanes gets the result.  One tree: lane sums ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)), then
-// (l0 + l1) + (l2 + l3); no fused multiply-adds (the same bits whatever code surrounds the call).
+// Every one of the 4 lanes gets the result.  One tree, written on PAIRS (w[i] = values 2i, 2i + 1: v_pk_add_f32 / v_pk_mul_f32 take two
+// fp32 per instruction, and in f32 every VALU instruction of an epilogue is matrix-pipe time): lane sums
+// ((v0 + v2) + (v4 + v6)) + ((v1 + v3) + (v5 + v7)), then (l0 + l1) + (l2 + l3); no fused multiply-adds (the same bits whatever code
+// surrounds the call).
 template <bool GROUPS>
 TAMF_DEV float ln_sum4(float p) {
   if constexpr (GROUPS) {
@@ -472,19 +479,20 @@ TAMF_DEV float ln_sum4(float p) {
   }
 }
 template <bool GROUPS>
-TAMF_DEV float2 ln_block_partial(const float (&v)[8]) {
+TAMF_DEV float2 ln_block_partial(const tamf_f32x2 (&w)[4]) {
 #pragma clang fp contract(off)
-  const float p = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  const float S = ln_sum4<GROUPS>(p);
+  const tamf_f32x2 s = (w[0] + w[1]) + (w[2] + w[3]);
+  const float S = ln_sum4<GROUPS>(s.x + s.y);
   const float mb = S * 0.03125f;
-  float q[8];
+  const tamf_f32x2 mb2 = {mb, mb};
+  tamf_f32x2 q[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float dlt = v[j] - mb;
+  for (int j = 0; j < 4; ++j) {
+    const tamf_f32x2 dlt = w[j] - mb2;
     q[j] = dlt * dlt;
   }
-  const float qq = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-  return make_float2(S, ln_sum4<GROUPS>(qq));
+  const tamf_f32x2 qq = (q[0] + q[1]) + (q[2] + q[3]);
+  return make_float2(S, ln_sum4<GROUPS>(qq.x + qq.y));
 }
 
 // (mean, rstd) of rows [r0, r0 + rows) into out[0 .. rows) (LDS), by NT threads, 4 lanes (a quad) per row: lane q of the quad takes the

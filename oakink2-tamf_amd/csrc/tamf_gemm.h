@@ -255,15 +255,17 @@ struct EpiBiasAct {
 // The same projection as two clip-tile launches (tamf_gemm_clip.h): EpiQK = its Q and K columns (register form only), EpiVt =
 // its V columns with the MFMA operands exchanged, so that a lane ends up with runs of consecutive KEYS of one feature - what
 // a V^T row stores.  Same operations per element as EpiQKV::run, i.e. the same bits.
-template <class Op>
+template <class Op, bool LN = false>
 struct EpiQK {
-  const float* bias;  // [2d] (the Q and K parts of in_proj_bias)
+  const float* bias;  // [2d] (the Q and K parts of in_proj_bias; LN: of c2)
   typename Op::elem_t* qk;
   int d;
   float qscale;
   int act;  // (ACT_NONE; the register epilogue dispatches on it)
   EpiCtl ctl;
-  static constexpr bool ROWSTATS = false;
+  LnStats ln{};
+  static constexpr bool ROWSTATS = LN;
+  static constexpr bool STAGE_AFF = true;
   static constexpr bool PREFETCH = false;
   static constexpr int LANE_CHUNK = Op::PREC == 0 ? 4 : 8;
   static constexpr bool TRANSPOSED = false;
@@ -275,18 +277,34 @@ struct EpiQK {
     for (int j = 0; j < N; ++j) v[j] = fmaf(v[j], ctl.wscale, bi[j]) * sc;
     Op::template store_rc<N>(qk, (long)gr * (2 * d) + gn, v, am);
   }
+  // (deferred LayerNorm of the row: st.x = its factor rstd ws - EpiQKV<Op, true>::proj, the same operations)
+  template <int N>
+  TAMF_DEV void finish_ln(int, int gr, int gn, float (&v)[N], const float (&bi)[N], const float (&)[N], float2 st, float& am) const {
+    const float sc = (gn < d) ? qscale : 1.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = aff(v[j], st, bi[j]) * sc;
+    Op::template store_rc<N>(qk, (long)gr * (2 * d) + gn, v, am);
+  }
   TAMF_DEV void flag(float am) const { Op::range_flag(am, ctl.status); }
   template <int N>
   TAMF_DEV void lane_cols(int gn, float (&bi)[N]) const { g_loadn<N>(bias + gn, bi); }
+  template <int N>
+  TAMF_DEV void lane_cols_ln(int gn, float (&bi)[N], float (&ci)[N]) const {
+    g_loadn<N>(bias + gn, bi);
+#pragma unroll
+    for (int j = 0; j < N; ++j) ci[j] = 0.f;
+  }
 };
-template <class Op>
+template <class Op, bool LN = false>
 struct EpiVt {
-  const float* bias;  // [d] (the V part of in_proj_bias)
+  const float* bias;  // [d] (the V part of in_proj_bias; LN: of c2)
   typename Op::elem_t* vt;
   int H, hd, Skp;
   int act;
   EpiCtl ctl;
-  static constexpr bool ROWSTATS = false;
+  LnStats ln{};
+  static constexpr bool ROWSTATS = LN;  // (transposed: the staged row factors are indexed by the lane's KEYS, clip_store_vt)
+  static constexpr bool STAGE_AFF = true;
   static constexpr bool PREFETCH = false;
   static constexpr int LANE_CHUNK = 4;  // (W rows staged in their natural order)
   static constexpr bool TRANSPOSED = true;
@@ -859,10 +877,10 @@ struct EpiResid {
   static constexpr bool ROWSTATS = true;
   static constexpr bool STAGE_AFF = false;  // the kernel stages (mean, rstd): the residual is normalised itself, not a product of it
   static constexpr bool PREFETCH = true;  // the register epilogue requests row tile mi + 1's residual piece ahead of row tile mi's stores
-  static_assert(Op::PREC != 0, "the deferred LayerNorm serves the 16-bit modes (f32 keeps the reference's operation order)");
   static constexpr int LANE_CHUNK = 8;
   static constexpr bool TRANSPOSED = false;
-  static constexpr int CHUNK_STORES = 2 + (Op::SPLIT ? 2 : 1) + 1;  // fp32 row piece (2 x 16 bytes), operand piece(s), block statistics
+  // fp32 row piece (2 x 16 bytes), operand piece(s) (f32: the residual stream IS the operand, xop = null), block statistics
+  static constexpr int CHUNK_STORES = 2 + (Op::PREC == 0 ? 0 : Op::SPLIT ? 2 : 1) + 1;
   TAMF_DEV void flag(float am) const { Op::range_flag(am, ctl.status); }
   template <int N>
   TAMF_DEV void lane_cols_ln(int gn, float (&bi)[N], float (&ci)[N]) const {
@@ -874,15 +892,25 @@ struct EpiResid {
   template <bool GROUPS>
   TAMF_DEV void finish_piece(int gr, int gn, float (&v)[8], const float (&u)[8], const float (&bi)[8], const float (&ci)[8], float2 st,
                              float& am) const {
+    // (on pairs: v_pk_add / v_pk_mul / v_pk_fma_f32 - the same IEEE operations per element as the scalar form)
+    tamf_f32x2 w[4];
+    {
+#pragma clang fp contract(off)
+      const tamf_f32x2 mean2 = {st.x, st.x}, rstd2 = {st.y, st.y}, ws2 = {ctl.wscale, ctl.wscale};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float y = fmaf(__fmul_rn(__fsub_rn(u[j], st.x), st.y), ci[j], bi[j]);  // (the LayerNorm formula of every kernel here)
-      v[j] = fmaf(v[j], ctl.wscale, y);
+      for (int j = 0; j < 4; ++j) {
+        const tamf_f32x2 uu = {u[2 * j], u[2 * j + 1]}, g2 = {ci[2 * j], ci[2 * j + 1]}, b2 = {bi[2 * j], bi[2 * j + 1]};
+        const tamf_f32x2 a2 = {v[2 * j], v[2 * j + 1]};
+        const tamf_f32x2 y = __builtin_elementwise_fma((uu - mean2) * rstd2, g2, b2);  // (the LayerNorm formula of every kernel here)
+        w[j] = __builtin_elementwise_fma(a2, ws2, y);
+        v[2 * j] = w[j].x;
+        v[2 * j + 1] = w[j].y;
+      }
     }
     const long o = (long)gr * d + gn;
     g_store8(x + o, v);
-    Op::template store_rc<8>(xop, o, v, am);
-    const float2 p = ln_block_partial<GROUPS>(v);
+    if constexpr (Op::PREC != 0) Op::template store_rc<8>(xop, o, v, am);
+    const float2 p = ln_block_partial<GROUPS>(w);
     if ((gn & 31) == 0) part_out[(long)gr * (d >> 5) + (gn >> 5)] = p;
   }
   template <int N>

@@ -457,20 +457,31 @@ TAMF_DEV void clip_store_rows(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], 
 // (even: XSUB is), MS its row tiles.
 template <class Op, class C, int NI, int FIRST, int MS, class Epi>
 TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], int g, int Sp, int b, int eg0 /* feature of ni = 0 */,
-                            const float (&bb)[NI]) {
+                            const float (&bb)[NI], const float2* rs /* Epi::ROWSTATS: the staged row factors of the clip's tokens */) {
   static_assert(FIRST % 2 == 0, "row-tile pairs must not straddle the X / Y split");
   float am = 0.f;
+  // acc ws + bias, or - deferred LayerNorm of the token's row - acc ra[token] + c2: the factors of the lane's four tokens of a row tile
+  // come from LDS once per row tile (they are the same for every feature tile ni)
+  auto factors = [&](int tok, float (&ra)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (Epi::ROWSTATS) ra[j] = rs[tok + j].x;
+      else ra[j] = epi.ctl.wscale;
+    }
+  };
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bb[ni]));  // (one wait, ahead of the stores)
   if constexpr (Op::PREC == 0) {
 #pragma unroll
     for (int mi = 0; mi < MS; ++mi) {
       const int tok = (FIRST + mi) * 16 + 4 * g;
+      float ra[4];
+      factors(tok < Sp ? tok : 0, ra);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? fmaf(acc[mi][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = tok < Sp ? fmaf(acc[mi][ni][j], ra[j], bb[ni]) : 0.f;
         epi.template store_keys<4>(b, eg0 + 16 * ni, tok, v, am);
       }
     }
@@ -479,13 +490,16 @@ TAMF_DEV void clip_store_vt(const Epi& epi, const f32x4 (&acc)[C::MSUB0][NI], in
     for (int u = 0; u < (MS + 1) / 2; ++u) {
       const int s0 = FIRST + 2 * u;  // row tiles s0 and s0 + 1: keys 16 s0 + 4g + j and 16 (s0 + 1) + 4g + j
       const int tok0 = s0 * 16 + 4 * g, tok1 = tok0 + 16;
+      float ra0[4], ra1[4];
+      factors(tok0 < Sp ? tok0 : 0, ra0);
+      factors(tok1 < Sp && 2 * u + 1 < MS ? tok1 : 0, ra1);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = tok0 < Sp ? fmaf(acc[2 * u][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
-          if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? fmaf(acc[2 * u + 1][ni][j], epi.ctl.wscale, bb[ni]) : 0.f;
+          v[j] = tok0 < Sp ? fmaf(acc[2 * u][ni][j], ra0[j], bb[ni]) : 0.f;
+          if (2 * u + 1 < MS) v[4 + j] = tok1 < Sp ? fmaf(acc[2 * u + 1][ni][j], ra1[j], bb[ni]) : 0.f;
           else v[4 + j] = 0.f;
         }
         epi.template store_keys<8>(b, eg0 + 16 * ni, (s0 >> 1) * 32 + 8 * g, v, am);
@@ -587,7 +601,6 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
   const int lane_col = wn0 + C::CHUNK * g;  // first of the lane's output columns inside the tile (clip_wperm)
   char* slot = smem + C::SCRATCH_OFF + wave * C::SCRATCH_WAVE + lane * 16;
   float2* const rstat = (float2*)(smem + C::STATS_OFF);  // [3][MT] row terms of the tile of round r: slot r % 3
-  static_assert(!(TR && Epi::ROWSTATS), "the transposed epilogue has no deferred-LayerNorm form");
 
   // The workgroup is persistent over its tiles (rounds of the grid) and treats their K tiles as ONE stream: interval j
   // belongs to K tile j % KT of round j / KT and lives in stage j % NS.  X multiplies K tile j in interval j and requests K tile
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           pre = true;
         }
         if constexpr (TR) {
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, 0, C::MSUBX>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb, rstat + (round % 3) * C::MT);
         } else {
           clip_settle(bi);
           if constexpr (Epi::ROWSTATS) clip_settle(ci);
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
           float bb[NI];
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) bb[ni] = epi.bias[n0 + wn0 + lr + 16 * ni];
-          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb);
+          if (!(TAMF_ABL(ga.abl) & 4)) clip_store_vt<Op, C, NI, C::MSUBX, C::MSUBY>(epi, acc, g, ga.Sp, b, n0 + wn0 + lr, bb, rstat + (round % 3) * C::MT);
         } else {
           float bi[C::NCHUNK][C::CHUNK];
           float ci[C::NCHUNK][C::CHUNK];

@@ -540,15 +540,19 @@ static hipError_t prepare_clip() {
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::prepare()) != hipSuccess) return e;
-  if constexpr (Op::PREC != 0) {  // deferred LayerNorm: FFN1 with the row statistics, the two residual GEMMs
-    if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::prepare()) != hipSuccess) return e;
-    if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NS>::prepare()) != hipSuccess) return e;
-    if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::prepare()) != hipSuccess) return e;
-  }
+  // deferred LayerNorm: FFN1 with the row statistics, the two residual GEMMs
+  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NS>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::prepare()) != hipSuccess) return e;
   if constexpr (Op::PREC == 0 || NS == 13) {  // the QKV projection on clip tiles: f32 (the 16-bit modes: A/B partner at T = 196 only)
     if ((e = ClipLaunch<Op, 2, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
     if ((e = ClipLaunch<Op, 4, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
     if ((e = ClipLaunch<Op, 2, EpiVt<Op>, NS>::prepare()) != hipSuccess) return e;
+  }
+  if constexpr (Op::PREC == 0) {  // ... and with the deferred LayerNorm of its input rows
+    if ((e = ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::prepare()) != hipSuccess) return e;
+    if ((e = ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::prepare()) != hipSuccess) return e;
   }
   return hipSuccess;
 }
@@ -560,11 +564,9 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiHead<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiStoreF32, true>::prepare()) != hipSuccess) return e;
-  if constexpr (Op::PREC != 0) {
-    if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
-    if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
-    if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
-  }
+  if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
@@ -774,7 +776,9 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   ctx->P = arch->kind == TAMF_KIND_G ? 5 : 3;
   ctx->XK = arch->kind == TAMF_KIND_G ? 128 : round_up(arch->input_dim + arch->h2o_dim, 64);
   ctx->EB = precision == TAMF_PREC_BF16 ? 2 : 4;
-  ctx->defer_ln = precision != TAMF_PREC_F32;  // f32 keeps the reference's operation order (LayerNorm where the reference has it)
+  // (selection bit 4096, set before the context is created: f32 with the LayerNorms where the reference has them - GEMM + LayerNorm
+  // kernel, the form of rounds 2 - 5 - as the A/B partner of the deferred form)
+  ctx->defer_ln = precision != TAMF_PREC_F32 || !(g_sel & 4096);
   ctx->layers.resize(ctx->L);
 
   auto bail = [&](int rc) {
@@ -1284,8 +1288,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
   bool deferred_done = false;
-  if constexpr (Op::PREC != 0) {
-    // Deferred LayerNorm (tamf_device.h): the residual stream X / X_op holds the UN-normalised sums; five launches per layer
+  {
+    // Deferred LayerNorm (tamf_device.h): the residual stream X / X_op holds the UN-normalised sums; five launches per layer (f32: six,
+    // the QKV projection as two clip launches)
     if (ctx->defer_ln) {
       const int NB = d / 32;
       const float inv_d = 1.0f / (float)d;
@@ -1295,9 +1300,31 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         const LnStats ln_ff{ctx->stat_att, NB, inv_d, 1e-5f};               // ... in front of the feed-forward block
         {
           GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
-          EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, ln_in};
-          HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-          mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
+          bool on_clip = false;
+          if constexpr (Op::PREC == 0) {  // f32: the Q | K columns and the V columns as two clip launches (see the other branch)
+            if (!(g_sel & 64) && ctx->hd == 128) {
+              TAMF_CLIP_NSUB(Sp, {
+                if (ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::applies(B, Sp, 2 * d, d) && ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::applies(B, Sp, d, d)) {
+                  EpiQK<Op, true> eq{w.c2_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}, ln_in};
+                  if (ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::applies(B, Sp, 2 * d, d))
+                    HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+                  else
+                    HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+                  const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
+                  EpiVt<Op, true> ev{w.c2_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}, ln_in};
+                  mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
+                  HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
+                  mark("gemm_v", BS * 2.0 * dd * dd);
+                  on_clip = true;
+                }
+              })
+            }
+          }
+          if (!on_clip) {
+            EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, ln_in};
+            HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+            mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
+          }
         }
         {
           AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H, 0};
@@ -1983,8 +2010,8 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
       EpiQKV<Op> ep{vec, o, o2, d, d / 128, 128, 208, 224, 0.1f};
       e = gemm128<Op>(ga, ep, st);
     } else if (epi_kind >= 10 && epi_kind <= 12) {
-      // the deferred-LayerNorm forms (16-bit modes): 10 = FFN1 with the row terms, 11 = QKV with the row terms, 12 = residual GEMM
-      if constexpr (Op::PREC != 0) {
+      // the deferred-LayerNorm forms: 10 = FFN1 with the row terms, 11 = QKV with the row terms, 12 = residual GEMM
+      {
         const LnStats ln{(const float2*)x, K / 32, 1.0f / (float)K, 1e-5f};  // (any finite numbers: x is M x N >= M x K / 16 floats)
         if (epi_kind == 10) {
           EpiBiasAct<Op, true> ep{vec, nullptr, 0, o, N, ACT_GELU, {}, ln};
@@ -1999,8 +2026,6 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
           EpiResid<Op> ep{vec, vec + N, x, o, N, (float2*)o2, ACT_NONE, {}, LnStats{nullptr, N / 32, 1.0f / (float)N, 1e-5f}};
           e = M % 208 == 0 ? launch_resid<Op>(ga, ep, M / 208, 208, st) : gemm128<Op>(ga, ep, st);
         }
-      } else {
-        e = hipErrorInvalidValue;
       }
     } else {
       EpiBiasAct<Op> ep{vec, nullptr, 0, o, N, ACT_GELU};

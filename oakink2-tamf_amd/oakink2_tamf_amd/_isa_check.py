@@ -61,8 +61,8 @@ def expected(op, nsub, ni, xsub, epi):
             ch = 4 if prec == 0 else 8
             cs = ch // 4 + (2 if split else 1)
             hook = 2 + (2 if (split or prec == 0) else 1)
-        elif epi == "EpiResid":  # deferred LayerNorm: fp32 row piece (2 x 16 bytes) + operand piece(s) + the block statistics (8 bytes)
-            ch, cs = 8, 2 + (2 if split else 1) + 1
+        elif epi == "EpiResid":  # deferred LayerNorm: fp32 row piece (2 x 16 bytes) + operand piece(s) (f32: none, the row piece is the operand) + the block statistics (8 bytes)
+            ch, cs = 8, 2 + (0 if prec == 0 else 2 if split else 1) + 1
         else:  # EpiBiasAct (with or without the deferred LayerNorm of its rows), EpiQK: operand output
             ch, cs = (4 if prec == 0 else 8), (2 if split else 1)
         nchunk = 4 * ni // ch

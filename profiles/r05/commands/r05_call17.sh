@@ -1,0 +1,17 @@
+#!/bin/bash
+# f32 with the LayerNorms deferred + pair-wise residual epilogue (GELU back on libm erff): the invariance / parity subsets in all modes,
+# loops against the c4cd61f library (lib A) alternating on one box
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r05
+{
+python __graft_entry__.py smoke 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_hip_forward.py tests/test_hip_robustness.py -x -q -m gpu 2>&1 | tail -4
+timeout 1500 python -m pytest tests/test_hip_fullsize.py -q -m gpu -k "equals_clip_alone or vs_oracle or same_bits" 2>&1 | tail -8
+echo "== per-kernel, f32: working tree"
+python tools/step_ab.py f32 64 2>&1 | grep -v amdgpu.ids
+python tools/step_ab.py f32 32 2>&1 | grep -v amdgpu.ids
+echo "== loops, alternating (A = c4cd61f)"
+bash tools/ab_loop.sh "f32" 64
+bash tools/ab_loop.sh "f32" 32
+} > gpurun_out/r05/ab_f32_deferred_c17.txt 2>&1
+tail -30 gpurun_out/r05/ab_f32_deferred_c17.txt
