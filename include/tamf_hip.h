@@ -240,10 +240,14 @@ int tamf_refine_profile(tamf_ctx* ctx, const float* sample_pose_repr_dev, const 
  * operands are converted to `precision` on the fly by the library's own pack kernels. */
 int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
                    const float* bias_dev, int32_t act, float* c_dev, void* stream);
-/* y = LayerNorm(resid + A.W^T + bias) * gamma + beta with N == latent width (128/256/512). */
-int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
-                      const float* bias_dev, const float* resid_dev, const float* gamma_dev,
-                      const float* beta_dev, float* y_dev, void* stream);
+/* The residual GEMM of an encoder sublayer as the step runs it (the LayerNorm of its INPUT deferred, EpiResid; N == latent width,
+ * 128 / 256 / 512; reference: nn.TransformerEncoderLayer's x + sublayer(x) behind norm1 / norm2, interaction_segment_mdm.py:63-70):
+ *   x[m][n] <- ((x[m][n] - mean[m]) rstd[m] gamma[n] + bb[n]) + (A . W^T)[m][n]        (in place, f32)
+ * with (mean, rstd) of row m from stats_in[m][N / 32] = (S_b, Q_b), the sum and the sum of squares about its own mean of every
+ * 32-column block of the row on entry (null: no LayerNorm in front, gamma = ones expected), and stats_out the same of the row on return. */
+int tamf_test_gemm_resid(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                         const float* bb_dev, const float* gamma_dev, const float* stats_in_dev, float* x_dev,
+                         float* stats_out_dev, void* stream);
 /* out[b,s,h*hd+e] = softmax(q k^T / sqrt(hd)) v per (b,h); qkv_dev: (B, S, 3*H*hd) f32 packed [q|k|v]. */
 int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
                         float* out_dev, void* stream);

@@ -410,38 +410,8 @@ TAMF_DEV float wave_reduce(float v) {
 }
 TAMF_DEV float wave_sum(float v) { return wave_reduce<RedSum>(v); }
 
-// Sum of a 512-wide row for the LayerNorm statistics, in ONE association order for every kernel that normalises such a row,
-// so that a clip's result does not depend on which kernel ran (batch-invariance tests).  The order is the one that is natural
-// for the clip-tile GEMM's in-register LayerNorm (tamf_gemm_clip.h, lane (wave nq, group g) holds columns
-// 128 c + 32 nq + 16 ni + 4 g + {0..3} of column tile c):
-//   quad  q = ((x0 + x1) + x2) + x3                                  4 consecutive columns
-//   a[g]  = q(ni = 0, g) + q(ni = 1, g)                              the two MFMA column tiles of a wave
-//   b[nq] = (a[0] + a[1]) + (a[2] + a[3])                            the 4 lane groups of a wave (permlane swaps)
-//   t[c]  = ((b[0] + b[1]) + b[2]) + b[3]                            the 4 waves of a 128-column tile
-//   S     = ((t[0] + t[1]) + t[2]) + t[3]                            the 4 column tiles = 4 workgroups
-// This function is the same tree for the wave-per-row kernels (lane l holds columns 8 l .. 8 l + 7: inside a row of 16 lanes,
-// lane r is wave nq = r / 4, column tile ni = (r % 4) / 2, groups g = 2 (r % 2) and 2 (r % 2) + 1).  IEEE addition commutes, so
-// only the shape of the tree matters, not which lane holds which operand.
-enum { DPP_ROW_SHARE0 = 0x150 };
-TAMF_DEV float ln_row_sum512(const float (&v)[8]) {
-  float q0 = ((v[0] + v[1]) + v[2]) + v[3];
-  float q1 = ((v[4] + v[5]) + v[6]) + v[7];
-  q0 = q0 + dpp_mov<DPP_XOR2>(q0);          // a[g] of this lane's two groups
-  q1 = q1 + dpp_mov<DPP_XOR2>(q1);
-  const float p = q0 + q1;                  // a[0] + a[1] (even lanes) / a[2] + a[3] (odd lanes)
-  const float b = p + dpp_mov<DPP_XOR1>(p); // b[nq], in all four lanes of the quad
-  const float t = ((dpp_mov<DPP_ROW_SHARE0 + 0>(b) + dpp_mov<DPP_ROW_SHARE0 + 4>(b)) + dpp_mov<DPP_ROW_SHARE0 + 8>(b)) +
-                  dpp_mov<DPP_ROW_SHARE0 + 12>(b);  // t[c], in all 16 lanes of row c
-  const int ti = __builtin_bit_cast(int, t);
-  const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 0));
-  const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 16));
-  const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 32));
-  const float t3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, 48));
-  return ((t0 + t1) + t2) + t3;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Deferred LayerNorm (round 5; the 16-bit arithmetic modes).
+// Deferred LayerNorm (round 5; every arithmetic mode).
 //
 // The reference's encoder layer is post-LN: x = LayerNorm(u), u = x_prev + sublayer(x_prev) (interaction_segment_mdm.py:63-70, torch
 // nn.TransformerEncoderLayer, eps 1e-5).  A LayerNorm needs whole rows, and no tiling of whole rows fills 256 CUs (rounds 2 - 4: the

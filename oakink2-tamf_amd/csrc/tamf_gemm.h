@@ -570,107 +570,6 @@ struct EpiSeqRows {
   }
 };
 
-// y = LayerNorm(resid + C + bias) * gamma + beta over the full row (BN == N == d); one wave per row.
-template <class Op>
-struct EpiLN {
-  const float* bias;
-  const float* resid;  // [M][d]
-  const float* gamma;
-  const float* beta;
-  float* xout;  // [M][d] (may alias resid: every row is read and written by the same wave)
-  typename Op::elem_t* xop;
-  float eps;
-  EpiCtl ctl;
-  static constexpr bool ROWSTATS = false;
-  static constexpr bool PREFETCH = false;
-  template <int BM, int BN, int NT>
-  TAMF_DEV void run(const float* Ct, int LDC, int m0, int n0, int M, int tid) const {
-    (void)n0;
-    constexpr int VPL = BN / 64;
-    constexpr int NW = NT / 64;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int c0 = lane * VPL;
-    float bi[VPL], ga[VPL], be[VPL];
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      bi[j] = bias[c0 + j];
-      ga[j] = gamma[c0 + j];
-      be[j] = beta[c0 + j];
-    }
-    // the residual rows of all of this wave's rows are requested first: issued inside the row loop each row would
-    // expose one full global-load latency (8 rows per wave = most of this epilogue's time)
-    constexpr int RPW = BM / NW;  // rows per wave
-    static_assert(BM % NW == 0, "rows per wave");
-    float rs[RPW][VPL];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      int gr = m0 + wave + i * NW;
-      gr = gr < M ? gr : M - 1;
-      const float* rp = resid + (long)gr * BN + c0;
-      if constexpr (VPL % 4 == 0) {
-#pragma unroll
-        for (int j = 0; j < VPL; j += 4) {
-          const float4 t = *(const float4*)(rp + j);
-          rs[i][j] = t.x; rs[i][j + 1] = t.y; rs[i][j + 2] = t.z; rs[i][j + 3] = t.w;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) rs[i][j] = rp[j];
-      }
-    }
-    float am = 0.f;
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int row = wave + i * NW;
-      const int gr = m0 + row;
-      if (gr >= M) break;
-      float v[VPL];
-      const float* cp = Ct + row * LDC + c0;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        v[j] = fmaf(cp[j], ctl.wscale, bi[j]) + rs[i][j];
-        s += v[j];
-      }
-      float mean, var;
-      if constexpr (VPL == 8) {  // 512 columns: the association order shared with the clip-tile LayerNorm (ln_row_sum512)
-#pragma clang fp contract(off)
-        mean = ln_row_sum512(v) * (1.0f / BN);
-        float dq[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const float dlt = v[j] - mean;
-          dq[j] = dlt * dlt;
-        }
-        var = ln_row_sum512(dq) * (1.0f / BN);
-      } else {
-        mean = wave_sum(s) * (1.0f / BN);
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const float dlt = v[j] - mean;
-          q += dlt * dlt;
-        }
-        var = wave_sum(q) * (1.0f / BN);
-      }
-      const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) v[j] = fmaf((v[j] - mean) * rstd, ga[j], be[j]);  // (explicit: the same in every LayerNorm)
-      float* op = xout + (long)gr * BN + c0;
-      if constexpr (VPL == 8) {
-        gst16f(op, v[0], v[1], v[2], v[3]);
-        gst16f(op + 4, v[4], v[5], v[6], v[7]);
-      } else if constexpr (VPL == 4) {
-        gst16f(op, v[0], v[1], v[2], v[3]);
-      } else {
-        *(float2*)op = make_float2(v[0], v[1]);
-      }
-      if (xop) Op::template store_rc<VPL>(xop, (long)gr * BN + c0, v, am);
-    }
-    Op::range_flag(am, ctl.status);
-  }
-};
-
 // output_process.poseFinal (+ bias, nan_to_num) fused with either the x0 write-out in the reference layout
 // (B, F, 1, T) or the DDPM reverse update of the frame-major sampler state.
 enum { HEAD_X0 = 0, HEAD_DDPM = 1, HEAD_RESIDUAL = 2 };
@@ -858,7 +757,7 @@ struct EpiStoreF32 {
   }
 };
 
-// Residual add of a post-LN sublayer with the LayerNorm of its INPUT deferred (tamf_device.h, "Deferred LayerNorm"; 16-bit modes):
+// Residual add of a post-LN sublayer with the LayerNorm of its INPUT deferred (tamf_device.h, "Deferred LayerNorm"):
 //   u_next[m][n] = ((u[m][n] - mean[m]) rstd[m] gamma[n] + bb[n]) + C[m][n] ws            bb = beta + bias of this GEMM
 // read from and written back to the fp32 residual stream in place (every element by one lane), stored as the operand of the next
 // GEMM, and summarised per 32-column block as (S_b, Q_b) for the LayerNorm that the consumers of u_next will apply.

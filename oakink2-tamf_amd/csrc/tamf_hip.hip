@@ -20,7 +20,6 @@
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
 #ifdef TAMF_BENCH  // the row-block LayerNorm GEMM of round 4 (measured, not faster: DESIGN.md): an A/B partner of the measurement builds only
-#include "tamf_gemm_rowblock.h"
 #endif
 #include "tamf_geom.h"
 #include "tamf_misc.h"
@@ -41,18 +40,15 @@ static std::string g_noctx_err;
 
 struct OperandBuf {
   void* p = nullptr;
-  void* packed = nullptr;  // fragment-major copy for the row-block kernels (tamf_gemm_rowblock.h): out-proj and FFN2 weights, d = 512
   float inv_scale = 1.0f;  // f16x3 weights are stored scaled by a power of two (upload_operand); this is its inverse, applied by the epilogue
 };
 
 struct LayerW {
   OperandBuf Win, Wout, W1, W2;
-  // deferred LayerNorm (16-bit modes; tamf_device.h): Win / W1 hold W diag(gamma) (I - 1 1^T / d), the consumers take c2 = W beta + b
+  // deferred LayerNorm (tamf_device.h): Win / W1 hold W diag(gamma) (I - 1 1^T / d), the consumers take c2 = W beta + b
   // in place of the bias, the residual adds take (gamma, beta + bias) of the LayerNorm their residual passes through
   float *c2_in = nullptr, *c2_ff = nullptr;
   float *g_att = nullptr, *bb_att = nullptr, *g_ffn = nullptr, *bb_ffn = nullptr;
-  float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
-  float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
 
 // What a captured step sequence depends on.  Seed, clip range, noise / dump tensors are NOT part of it: the kernels read
@@ -111,7 +107,6 @@ struct tamf_ctx {
   // activations
   int B = 0, T = 0, S = 0, Sp = 0, Skp = 0, M = 0;
   long Mmax = 0;
-  float* tmp32 = nullptr;  // [M][d] fp32 scratch of the two-kernel FFN2 form
   float *xs = nullptr, *cobj = nullptr, *X = nullptr, *pstatic = nullptr, *etmp = nullptr, *meanbuf = nullptr,
         *objfeat = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
@@ -126,7 +121,6 @@ struct tamf_ctx {
   unsigned host_status = 0;  // status bits raised on the host (TAMF_STATUS_F16_WEIGHT_RANGE at tamf_finalize_weights); never cleared
   std::string weight_note;   // ... and which tensor raised it
   // deferred LayerNorm: partial row statistics of the residual stream after the attention / feed-forward sublayer, [Mmax][d / 32]
-  bool defer_ln = false;
   float2 *stat_att = nullptr, *stat_ffn = nullptr;
   // graph
   hipStream_t cap_stream = nullptr;
@@ -296,11 +290,12 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 // 5-8 %).  Only the kernel benchmark hook (tamf_bench_gemm) overrides it.
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
-// 2 = FFN2 / out-proj on the 128 x 128 / LayerNorm-fused tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
-// 16 = out-proj as clip GEMM + LayerNorm kernel in every mode, 32 = FFN1 on 128-column clip tiles, 64 = QKV on the 128 x 128 tiles, 128 = QKV on clip tiles, 256 = FFN2 as clip GEMM + LayerNorm kernel in bf16 too,
-// 512 = streaming attention kernel in the 16-bit modes too, 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds,
-// 2048 = the LayerNorm-fused GEMMs on the row-block kernel (tamf_gemm_rowblock.h: weights streamed L2 -> registers; measured in round 4, not
-// faster: off by default; set by a tuning word whose low 20 bits are 0x7FFFF)
+// 2 = FFN2 / out-proj on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
+// 64 = f32: QKV on the 128 x 128 tiles, 512 = streaming attention kernel in the 16-bit modes too,
+// 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds.
+// (Rounds 2 - 5 also had 16 / 256 / 2048 / 4096: the LayerNorm-fused 64 x d tile, the GEMM + LayerNorm-kernel form and the row-block kernel
+// of the residual GEMMs - gone with the deferred LayerNorm, which every mode uses now; 32 / 128: clip-tile variants of FFN1 / QKV that
+// lost their A/B.  The bits are accepted and ignored.)
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
@@ -483,77 +478,22 @@ static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st
   }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
 }
-#ifdef TAMF_BENCH
-// Row-block kernel (tamf_gemm_rowblock.h): rows per workgroup = the smallest of 32 / 48 / 64 that still fits one round of the CUs
-// (fewer rows per workgroup = more CUs busy and less MFMA work behind the same weight stream); beyond one round: 64
-template <class Op, int MI>
-static hipError_t rowblock_launch1(const RowblockArgs<Op>& ra, const EpiLN<Op>& epi, hipStream_t st) {
-  constexpr int BM = MI * 16, SMEM = RowblockCfg<Op>::NSTG * BM * GEMM_BKB + 2 * BM * 16 * 4;
-  static bool done[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (!(dev >= 0 && dev < 64 && done[dev])) {
-    hipError_t e = hipFuncSetAttribute((const void*)rowblock_ln_kernel<Op, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) done[dev] = true;
-  }
-  hipLaunchKernelGGL((rowblock_ln_kernel<Op, MI>), dim3((ra.M + BM - 1) / BM), dim3(512), SMEM, st, ra, epi);
-  return hipGetLastError();
-}
-template <class Op>
-static bool rowblock_applies(const GemmArgs<Op>& ga, const void* packed) {
-  if (!packed || (g_sel & 1) || !(g_sel & 2048) || ga.N != 512 || (ga.K * Op::EB) % GEMM_BKB != 0) return false;
-  const int KT = (ga.K * Op::EB) / GEMM_BKB;
-  return KT >= 8 && !(KT & 1);
-}
-template <class Op>
-static hipError_t rowblock_launch(const GemmArgs<Op>& ga, const void* packed, const EpiLN<Op>& epi, hipStream_t st) {
-  const RowblockArgs<Op> ra{ga.A, ga.lda, (const char*)packed, ga.M, ga.K};
-  const int cus = g_wg_slots / 2;
-  if ((ga.M + 31) / 32 <= cus) return rowblock_launch1<Op, 2>(ra, epi, st);
-  if ((ga.M + 47) / 48 <= cus) return rowblock_launch1<Op, 3>(ra, epi, st);
-  return rowblock_launch1<Op, 4>(ra, epi, st);
-}
-#else
-template <class Op>
-static bool rowblock_applies(const GemmArgs<Op>&, const void*) { return false; }
-template <class Op>
-static hipError_t rowblock_launch(const GemmArgs<Op>&, const void*, const EpiLN<Op>&, hipStream_t) { return hipErrorNotSupported; }
-#endif
-template <class Op>
-static hipError_t gemm_ln(const GemmArgs<Op>& ga, const EpiLN<Op>& epi, hipStream_t st, const void* packed = nullptr) {
-  if (rowblock_applies<Op>(ga, packed)) return rowblock_launch<Op>(ga, packed, epi, st);
-  switch (ga.N) {
-    case 128: return GemmLaunch<Op, 64, 128, EpiLN<Op>>::launch(ga, epi, st);
-    case 256: return GemmLaunch<Op, 64, 256, EpiLN<Op>>::launch(ga, epi, st);
-    case 512:
-      // fewer 64-row blocks than 60 % of the CUs (B = 32: 104): 32-row blocks
-      if (!(g_sel & 1) && ((ga.M + 63) / 64) * 10 < (g_wg_slots / 2) * 6) return GemmLaunch<Op, 32, 512, EpiLN<Op>>::launch(ga, epi, st);
-      return GemmLaunch<Op, 64, 512, EpiLN<Op>>::launch(ga, epi, st);
-    default: return hipErrorInvalidValue;
-  }
-}
 // the clip-tile kernels of one clip length (NS whole-clip row tiles, NSP row tiles of a row part)
 template <class Op, int NS, int NSP>
 static hipError_t prepare_clip() {
   hipError_t e;
-  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NS>::prepare()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::prepare()) != hipSuccess) return e;
-  // deferred LayerNorm: FFN1 with the row statistics, the two residual GEMMs
+  // the encoder layers: FFN1 with the row factors of the deferred LayerNorm, the two residual GEMMs (whole clips / row parts)
   if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NS>::prepare()) != hipSuccess) return e;
   if ((e = ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::prepare()) != hipSuccess) return e;
-  if constexpr (Op::PREC == 0 || NS == 13) {  // the QKV projection on clip tiles: f32 (the 16-bit modes: A/B partner at T = 196 only)
-    if ((e = ClipLaunch<Op, 2, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
-    if ((e = ClipLaunch<Op, 4, EpiQK<Op>, NS>::prepare()) != hipSuccess) return e;
-    if ((e = ClipLaunch<Op, 2, EpiVt<Op>, NS>::prepare()) != hipSuccess) return e;
-  }
-  if constexpr (Op::PREC == 0) {  // ... and with the deferred LayerNorm of its input rows
+  if constexpr (Op::PREC == 0) {  // f32: the QKV projection on clip tiles (Q | K columns; V columns transposed)
     if ((e = ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::prepare()) != hipSuccess) return e;
     if ((e = ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::prepare()) != hipSuccess) return e;
     if ((e = ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::prepare()) != hipSuccess) return e;
   }
+  // plain fp32 product (tamf_test_gemm, tamf_bench_gemm)
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NS>::prepare()) != hipSuccess) return e;
+  if ((e = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::prepare()) != hipSuccess) return e;
   return hipSuccess;
 }
 template <class Op>
@@ -567,15 +507,11 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 128, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 256, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 32, 512, EpiLN<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = prepare_clip<Op, 13, 7>()) != hipSuccess) return e;
   if ((e = prepare_clip<Op, 11, 6>()) != hipSuccess) return e;
-  if ((e = ClipLaunch<Op, 2, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;  // (A/B partner and test hook, T = 196 only)
+  if ((e = ClipLaunch<Op, 4, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;  // (tamf_bench_gemm: FFN1 without the row factors, T = 196)
   if ((e = ClipLaunch<Op, 4, EpiStoreF32>::prepare()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)attn_kernel<Op, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                AttnCfg<Op, 64>::SMEM)) != hipSuccess) return e;
@@ -716,7 +652,6 @@ static int alloc_workspaces(tamf_ctx* ctx, int max_batch, int max_frames) {
   A(alloc_operand(ctx, &ctx->Vt_op, (long)max_batch * d * Skpmax, true));
   A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
   A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
-  A(dev_alloc(ctx, (void**)&ctx->tmp32, Mmax * d * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
   const long meansz = std::max<long>((long)max_batch * std::max(ctx->arch.obj_embed_dim, ctx->arch.hand_shape_dim),
@@ -727,10 +662,8 @@ static int alloc_workspaces(tamf_ctx* ctx, int max_batch, int max_frames) {
   A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
   A(dev_alloc(ctx, (void**)&ctx->objnum_dev, (long)max_batch * 4, true));
-  if (ctx->defer_ln) {
-    A(dev_alloc(ctx, (void**)&ctx->stat_att, Mmax * (d / 32) * 8, true));
-    A(dev_alloc(ctx, (void**)&ctx->stat_ffn, Mmax * (d / 32) * 8, true));
-  }
+  A(dev_alloc(ctx, (void**)&ctx->stat_att, Mmax * (d / 32) * 8, true));  // block statistics of the residual stream (deferred LayerNorm)
+  A(dev_alloc(ctx, (void**)&ctx->stat_ffn, Mmax * (d / 32) * 8, true));
   A(dev_alloc(ctx, (void**)&ctx->loop_params, sizeof(LoopParams), true));
 #undef A
   g_alloc_tag = "(weights / tables)";
@@ -776,9 +709,6 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   ctx->P = arch->kind == TAMF_KIND_G ? 5 : 3;
   ctx->XK = arch->kind == TAMF_KIND_G ? 128 : round_up(arch->input_dim + arch->h2o_dim, 64);
   ctx->EB = precision == TAMF_PREC_BF16 ? 2 : 4;
-  // (selection bit 4096, set before the context is created: f32 with the LayerNorms where the reference has them - GEMM + LayerNorm
-  // kernel, the form of rounds 2 - 5 - as the A/B partner of the deferred form)
-  ctx->defer_ln = precision != TAMF_PREC_F32 || !(g_sel & 4096);
   ctx->layers.resize(ctx->L);
 
   auto bail = [&](int rc) {
@@ -849,7 +779,7 @@ extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_fra
   for (void* p : ctx->ws_allocs) (void)hipFree(p);
   ctx->ws_allocs.clear();
   ctx->guards.erase(std::remove_if(ctx->guards.begin(), ctx->guards.end(), [](const GuardRec& g) { return g.ws; }), ctx->guards.end());
-  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = ctx->etmp = ctx->meanbuf = ctx->objfeat = ctx->tmp32 = nullptr;
+  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = ctx->etmp = ctx->meanbuf = ctx->objfeat = nullptr;
   ctx->xs_op = ctx->h1_op = ctx->X_op = ctx->QK_op = ctx->Vt_op = ctx->A_op = ctx->H_op = OperandBuf{};
   ctx->X_st = ctx->xs_st = nullptr;
   ctx->stat_att = ctx->stat_ffn = nullptr;
@@ -857,18 +787,6 @@ extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_fra
   ctx->B = ctx->T = ctx->S = ctx->Sp = ctx->Skp = ctx->M = 0;
   return alloc_workspaces(ctx, max_batch, max_frames);
 }
-
-#ifdef TAMF_BENCH
-// fragment-major copy of a [512][K] operand matrix (tamf_gemm_rowblock.h)
-static int pack_rowblock(tamf_ctx* ctx, OperandBuf* ob, int K, hipStream_t st) {
-  const size_t bytes = (size_t)512 * K * ctx->EB;
-  TRY(dev_alloc(ctx, &ob->packed, bytes));
-  const long pieces = (long)bytes / 16;
-  TAMF_WITH_OP(ctx->prec, hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d(pieces), dim3(256), 0, st, (const typename Op::elem_t*)ob->p, K, K, (char*)ob->packed));
-  HIPCHK(ctx, hipGetLastError());
-  return 0;
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // weights
@@ -952,7 +870,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
   for (int l = 0; l < ctx->L; ++l) {
     const std::string p = "seqTransEncoder.layers." + std::to_string(l);
     LayerW& w = ctx->layers[l];
-    if (ctx->defer_ln) {
+    {
       // Deferred LayerNorm: fold the gain AND the centring of the LayerNorm in front of a GEMM into its weight, W'' = W diag(gamma) (I - 1 1^T / d)
       // (fp64: every row of W diag(gamma) minus its own mean), c2 = W beta + bias; the residual adds take gamma and beta + bias of the
       // LayerNorm their residual input passes through.  Layer 0's attention block reads the encoder input itself: the plain weight.
@@ -993,26 +911,9 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
       }
       TRY(dev_upload(ctx, &w.g_ffn, ga.data(), ga.size()));
       TRY(dev_upload(ctx, &w.bb_ffn, bb.data(), bb.size()));
-    } else {
-      TRY(upload_operand(ctx, prec, R(p + ".self_attn.in_proj_weight"), 3 * d, d, d, &w.Win, (p + ".self_attn.in_proj_weight").c_str()));
-      TRY(upload_operand(ctx, prec, R(p + ".linear1.weight"), ff, d, d, &w.W1, (p + ".linear1.weight").c_str()));
     }
     TRY(upload_operand(ctx, prec, R(p + ".self_attn.out_proj.weight"), d, d, d, &w.Wout, (p + ".self_attn.out_proj.weight").c_str()));
     TRY(upload_operand(ctx, prec, R(p + ".linear2.weight"), d, ff, ff, &w.W2, (p + ".linear2.weight").c_str()));
-#ifdef TAMF_BENCH
-    if (d == 512 && (g_sel & 2048)) {  // fragment-major copies for the row-block LayerNorm GEMMs (A/B selection, set BEFORE the weights are finalised)
-      TRY(pack_rowblock(ctx, &w.Wout, d, st));
-      TRY(pack_rowblock(ctx, &w.W2, ff, st));
-    }
-#endif
-    TRY(upload_f32(ctx, p + ".self_attn.in_proj_bias", &w.b_in));
-    TRY(upload_f32(ctx, p + ".self_attn.out_proj.bias", &w.b_out));
-    TRY(upload_f32(ctx, p + ".linear1.bias", &w.b1));
-    TRY(upload_f32(ctx, p + ".linear2.bias", &w.b2));
-    TRY(upload_f32(ctx, p + ".norm1.weight", &w.g1));
-    TRY(upload_f32(ctx, p + ".norm1.bias", &w.be1));
-    TRY(upload_f32(ctx, p + ".norm2.weight", &w.g2));
-    TRY(upload_f32(ctx, p + ".norm2.bias", &w.be2));
   }
   // fused input weight: input_merge.0[:, :d] . poseEmbedding (and, for R, input_merge.0[:, 2d:] . h2o embedding)
   {
@@ -1055,7 +956,7 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     std::vector<float> wf((size_t)ctx->XN * d, 0.f), bfp(ctx->XN, 0.f);
     memcpy(wf.data(), R("output_process.poseFinal.weight"), (size_t)F * d * 4);
     memcpy(bfp.data(), R("output_process.poseFinal.bias"), (size_t)F * 4);
-    if (ctx->defer_ln) {  // the encoder's last LayerNorm, deferred into the head: W_f diag(gamma) (I - 1 1^T / d), c2 = W_f beta + b_f
+    {  // the encoder's last LayerNorm, deferred into the head: W_f diag(gamma) (I - 1 1^T / d), c2 = W_f beta + b_f
       const std::string pl = "seqTransEncoder.layers." + std::to_string(ctx->L - 1);
       const float *g = R(pl + ".norm2.weight"), *be = R(pl + ".norm2.bias");
       for (int n = 0; n < F; ++n) {
@@ -1244,17 +1145,6 @@ static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, i
   return gemm128<Op>(ga, ep, st);
 }
 
-// second kernel of the two-kernel form of a LayerNorm-fused GEMM: X = LayerNorm(tmp32 + X) (+ operand)
-template <class Op>
-static void launch_residual_ln(tamf_ctx* ctx, const float* gamma, const float* beta, hipStream_t st) {
-  typedef typename Op::elem_t E;
-  const int M = ctx->M, d = ctx->d, rows_per_blk = 4;
-  dim3 grd((M + rows_per_blk - 1) / rows_per_blk);
-  if (d == 512) hipLaunchKernelGGL((residual_ln_kernel<Op, 8>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_st, M, 1e-5f, ctx->status);
-  else if (d == 256) hipLaunchKernelGGL((residual_ln_kernel<Op, 4>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_st, M, 1e-5f, ctx->status);
-  else hipLaunchKernelGGL((residual_ln_kernel<Op, 2>), grd, dim3(256), 0, st, ctx->tmp32, ctx->X, gamma, beta, ctx->X, (E*)ctx->X_st, M, 1e-5f, ctx->status);
-}
-
 template <class Op>
 static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_in, int t_off = 0) {
   typedef typename Op::elem_t E;
@@ -1287,11 +1177,10 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
-  bool deferred_done = false;
   {
     // Deferred LayerNorm (tamf_device.h): the residual stream X / X_op holds the UN-normalised sums; five launches per layer (f32: six,
     // the QKV projection as two clip launches)
-    if (ctx->defer_ln) {
+    {
       const int NB = d / 32;
       const float inv_d = 1.0f / (float)d;
       for (int l = 0; l < ctx->L; ++l) {
@@ -1359,138 +1248,6 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
           mark("gemm_ffn2", BS * 2.0 * dd * ff);
         }
       }
-      deferred_done = true;
-    }
-  }
-  if (!deferred_done)
-  for (int l = 0; l < ctx->L; ++l) {
-    const LayerW& w = ctx->layers[l];
-    {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
-      // clip tiles of 128 columns = one head of Q, K or V: the Q and K columns as one launch (8 tiles per clip), the V columns
-      // as a second one with the MFMA operands exchanged (V^T rows straight from the accumulators); else the 128 x 128 tiles
-      // (f32: 174.5 against 190 us at B = 64; the 16-bit modes: 62.5 against 62 us, they stay on the 128 x 128 tiles; 128 = force)
-      bool on_clip = false;
-      if (((Op::PREC == 0 && !(g_sel & 64)) || (g_sel & 128)) && ctx->hd == 128) {
-        TAMF_CLIP_NSUB(Sp, {
-          if constexpr (Op::PREC == 0 || NS == 13) {
-            if (ClipLaunch<Op, 2, EpiQK<Op>, NS>::applies(B, Sp, 2 * d, d) && ClipLaunch<Op, 2, EpiVt<Op>, NS>::applies(B, Sp, d, d)) {
-              EpiQK<Op> eq{w.b_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}};
-              if (ClipLaunch<Op, 4, EpiQK<Op>, NS>::applies(B, Sp, 2 * d, d))  // the Q | K columns on 256-column tiles where they fill their rounds (f32, B = 64: 174.5 against 179 us)
-                HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
-              else
-                HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
-              const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
-              EpiVt<Op> ev{w.b_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}};
-              mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
-              HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op>, NS>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
-              mark("gemm_v", BS * 2.0 * dd * dd);
-              on_clip = true;
-            }
-          }
-        })
-      }
-      if (!on_clip) {
-        EpiQKV<Op> ep{w.b_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}};
-        HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-        mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
-      }
-    }
-    {
-      AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H, 0};
-      HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
-      mark("attention", 4.0 * B * (double)S * S * dd);
-    }
-    {
-      GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
-      // f32: clip tiles + LayerNorm kernel (103 -> 62 + 16 us at B = 64); the 16-bit modes: the fused LDS-staged 64 x d tile (40 against
-      // 25 + 17 us).  Selection bit 16 forces the two-kernel form, 2048 the row-block kernel (tamf_gemm_rowblock.h, round 4: measured,
-      // not faster - f16x3 41 against 39 us here, FFN2 112 against 72 + 17 us - DESIGN.md section 6).
-      bool on_clip = false;
-      const bool ln_underfilled = ((M + 63) / 64) * 100 < (g_wg_slots / 2) * 70;  // the fused 64 x d LayerNorm tile fills < 70 % of the CUs
-      const bool rb = rowblock_applies<Op>(ga, w.Wout.packed) && !(g_sel & 16);
-      // Round 4: at 32 clips per GPU (whole-clip tiles on at most half of the CUs) the split modes take the two-kernel form too, on the
-      // 7 + 6 / 6 + 5 row-part tiles: 15.0 + 8.4 against 28.0 us for the fused 32-row tile (f16x3; bf16 9.0 + 6.7 against 15.6: stays fused)
-      if (!rb && !(g_sel & 2) && ctx->tmp32) {
-        TAMF_CLIP_NSUB(Sp, {
-          const bool parts = ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, d);  // (at most half of the CUs would get a whole clip: 32 clips per GPU)
-          // ... and whenever the fused 64-row tile would leave more than 30 % of the CUs idle in its single round (T = 160 at 64 clips:
-          // 168 blocks on 256 CUs; whole-clip tiles of 11 row tiles are exactly one round): 17.8 + 12.9 against 33.7 us (f16x3)
-          const bool two_kernel = Op::PREC == 0 || (g_sel & 16) || (Op::SPLIT && (parts || ln_underfilled));
-          if (two_kernel && (parts || ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, d))) {
-            EpiStoreF32 ep{w.b_out, ctx->tmp32, d, ACT_NONE, {w.Wout.inv_scale, ctx->status}};
-            if (parts) HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
-            else HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, d, d, ep, st)));
-            mark("gemm_outproj", BS * 2.0 * dd * dd);
-            launch_residual_ln<Op>(ctx, w.g1, w.be1, st);
-            mark("outproj_residual_ln", 0.0);
-            on_clip = true;
-          }
-        })
-      }
-      if (!on_clip) {
-        EpiLN<Op> ep{w.b_out, ctx->X, w.g1, w.be1, ctx->X, (E*)ctx->X_st, 1e-5f, {w.Wout.inv_scale, ctx->status}};
-        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st, w.Wout.packed));
-        mark("gemm_outproj_ln", BS * 2.0 * dd * dd);
-      }
-    }
-    {
-      GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
-      EpiBiasAct<Op> ep{w.b1, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}};
-      bool on_clip = false;
-      if ((g_sel & 32) && ClipLaunch<Op, 2, EpiBiasAct<Op>>::applies(B, Sp, ff, d)) {  // A/B: 128-column tiles (half the bytes per store burst)
-        HIPCHK(ctx, (ClipLaunch<Op, 2, EpiBiasAct<Op>>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
-        on_clip = true;
-      } else if (!(g_sel & 8)) {
-        TAMF_CLIP_NSUB(Sp, {
-          if (ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::applies(B, Sp, ff, d)) {
-            HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
-            on_clip = true;
-          }
-        })
-      }
-      if (!on_clip) HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-      mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
-    }
-    {
-      GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
-      // GEMM + row-wise LayerNorm kernel: always in the split modes (the 64 x d LayerNorm tile streams the whole 4 MB weight panel
-      // through every CU), and in f32 when the clip tiles apply (64 x 512 f32 tiles reach 75 TFLOP/s, the clip tiles 113: 362 ->
-      // 257 us per layer at B = 64); the bf16 LayerNorm-fused tile stays (51 against 36 + 14 us).  Both forms add bias and
-      // residual and normalise in the same operation order, so a clip's result does not depend on which one ran.
-      // (split modes: from 50 % of the slots - at 32 clips per GPU 128 clip tiles beat 208 tiles of 128 x 128: 1.645 -> 1.60 ms per step)
-      // (selection bit 2048: the row-block kernel, LayerNorm inside, weights streamed L2 -> registers - A/B partner, see out-proj above)
-      int clip2 = 0;  // 1 = whole-clip tiles, 2 = row-part tiles
-      const bool rb = rowblock_applies<Op>(ga, w.W2.packed) && !(g_sel & 256);
-      // (bf16: the fused tile - unless it would leave more than 30 % of the CUs idle (T = 160 at 64 clips): 26.2 + 11.0 against 41.7 us)
-      const bool ln_underfilled = ((M + 63) / 64) * 100 < (g_wg_slots / 2) * 70;
-      if (!rb && (Op::SPLIT || Op::PREC == 0 || (g_sel & 256) || ln_underfilled) && !(g_sel & 2)) {
-        TAMF_CLIP_NSUB(Sp, {
-          if (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::applies_parts(B, Sp, d, ff)) clip2 = 2;  // (f32 at 32 clips per GPU ran the fused tile before round 4: 236 us)
-          else if (ClipLaunch<Op, 2, EpiStoreF32, NS>::applies(B, Sp, d, ff, Op::SPLIT ? 50 : 74)) clip2 = 1;
-        })
-      }
-      if (!rb && (Op::SPLIT || clip2) && ctx->tmp32) {
-        // clip tiles or 128 x 128 tiles (4x fewer weight bytes per CU than the 64 x d LayerNorm tile) + a row-wise LayerNorm kernel
-        EpiStoreF32 ep{w.b2, ctx->tmp32, d, ACT_NONE, {w.W2.inv_scale, ctx->status}};
-        // at most half of the CUs would get a whole-clip tile (32 clips per GPU: 128 tiles): the 7 + 6 (6 + 5 at T = 160) row-tile parts
-        // of every clip as tiles of their own fill the round (58 -> ~40 us; same bits)
-        if (clip2) {
-          TAMF_CLIP_NSUB(Sp, {
-            if (clip2 == 2) HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NSP, 2>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
-            else HIPCHK(ctx, (ClipLaunch<Op, 2, EpiStoreF32, NS>::launch(nullptr, ga.A, ff, ga.W, ff, B, Sp, d, ff, ep, st)));
-          })
-        } else {
-          HIPCHK(ctx, gemm128<Op>(ga, ep, st));
-        }
-        mark("gemm_ffn2", BS * 2.0 * dd * ff);
-        launch_residual_ln<Op>(ctx, w.g2, w.be2, st);
-        mark("ffn2_residual_ln", 0.0);
-      } else {
-        EpiLN<Op> ep{w.b2, ctx->X, w.g2, w.be2, ctx->X, (E*)ctx->X_st, 1e-5f, {w.W2.inv_scale, ctx->status}};
-        HIPCHK(ctx, gemm_ln<Op>(ga, ep, st, w.W2.packed));
-        mark("gemm_ffn2_ln", BS * 2.0 * dd * ff);
-      }
     }
   }
   {
@@ -1524,7 +1281,7 @@ static EpiHead<Op> make_head(tamf_ctx* ctx, int mode) {
   h.n_steps = ctx->n_steps;
   h.lp = ctx->loop_params;
   h.ctl = EpiCtl{ctx->Wf.inv_scale, ctx->status};
-  h.ln = LnStats{ctx->defer_ln ? ctx->stat_ffn : nullptr, ctx->d / 32, 1.0f / (float)ctx->d, 1e-5f};
+  h.ln = LnStats{ctx->stat_ffn, ctx->d / 32, 1.0f / (float)ctx->d, 1e-5f};
   return h;
 }
 
@@ -1835,7 +1592,7 @@ struct TmpBufs {
 
 template <class Op>
 static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, const float* bias, int act, float* c,
-                          const float* resid, const float* gamma, const float* beta, bool ln, hipStream_t st) {
+                          const float* gamma, const float2* stats_in, float2* stats_out, bool resid, hipStream_t st) {
   typedef typename Op::elem_t E;
   if (prepare_all<Op>() != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "prepare failed");
   const int Kp = round_up(K, 64);
@@ -1848,17 +1605,11 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   hipLaunchKernelGGL((pack_operand_kernel<Op>), grid1d((long)N * (Kp / 8)), dim3(256), 0, st, w, wo, (long)N, K, Kp);
   GemmArgs<Op> ga{ao, Kp, wo, Kp, M, N, Kp, 0};
   hipError_t e;
-  if (ln) {
-    EpiLN<Op> ep{bias, resid, gamma, beta, c, yo, 1e-5f};
-    char* packed = nullptr;
-#ifdef TAMF_BENCH
-    if (N == 512) {  // the row-block kernel reads a fragment-major copy of the weights (what tamf_finalize_weights prepares)
-      packed = (char*)tb.get((size_t)N * Kp * Op::EB);
-      if (!packed) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
-      hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d((long)N * Kp * Op::EB / 16), dim3(256), 0, st, wo, Kp, Kp, packed);
-    }
-#endif
-    e = gemm_ln<Op>(ga, ep, st, packed);
+  if (resid) {
+    // the residual GEMM of an encoder sublayer with the LayerNorm of its input deferred (EpiResid): c holds u on entry, u_next on return
+    EpiResid<Op> ep{bias, gamma, c, Op::PREC == 0 ? nullptr : yo, N, stats_out, ACT_NONE, {}, LnStats{stats_in, N / 32, 1.0f / (float)N, 1e-5f}};
+    const int sp = M % 208 == 0 ? 208 : (M % 168 == 0 ? 168 : 0);
+    e = sp ? launch_resid<Op>(ga, ep, M / sp, sp, st) : gemm128<Op>(ga, ep, st);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
     // M = n * 208 rows (T = 196) or n * 168 rows (T = 160): the clip-aligned tiles the encoder layers use (same selection as
@@ -1901,14 +1652,16 @@ extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K
   return 0;
 }
 
-extern "C" int tamf_test_gemm_ln(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
-                                 const float* bias_dev, const float* resid_dev, const float* gamma_dev,
-                                 const float* beta_dev, float* y_dev, void* stream) {
+extern "C" int tamf_test_gemm_resid(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
+                                    const float* bb_dev, const float* gamma_dev, const float* stats_in_dev, float* x_dev,
+                                    float* stats_out_dev, void* stream) {
   TAMF_LAUNCH_LOCK;
   if (M <= 0 || K <= 0 || !(N == 128 || N == 256 || N == 512)) return fail(nullptr, TAMF_ERR_INVALID, "N must be 128/256/512");
+  if (!a_dev || !w_dev || !bb_dev || !gamma_dev || !x_dev || !stats_out_dev) return fail(nullptr, TAMF_ERR_INVALID, "null argument");
   hipStream_t st = (hipStream_t)stream;
   if (precision < 0 || precision > TAMF_PREC_F16X3) return fail(nullptr, TAMF_ERR_INVALID, "unknown precision");
-  TAMF_WITH_OP(precision, return test_gemm_impl<Op>(M, N, K, a_dev, w_dev, bias_dev, 0, y_dev, resid_dev, gamma_dev, beta_dev, true, st));
+  TAMF_WITH_OP(precision, return test_gemm_impl<Op>(M, N, K, a_dev, w_dev, bb_dev, 0, x_dev, gamma_dev, (const float2*)stats_in_dev,
+                                                    (float2*)stats_out_dev, true, st));
   return 0;
 }
 
@@ -1983,22 +1736,13 @@ static int bench_gemm_impl(int epi_kind, int M, int N, int K, int iters, float* 
   hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(on / 8), dim3(256), 0, st, x, on, 3u);
   hipLaunchKernelGGL((fill_operand_kernel<OpF32>), grid1d(N * 4 / 8), dim3(256), 0, st, vec, (long)N * 4, 4u);
   GemmArgs<Op> ga{a, K, w, K, M, N, K, 0};
-  char* wpacked = nullptr;
-#ifdef TAMF_BENCH
-  if (epi_kind == 2 && N == 512) {
-    wpacked = (char*)tb.get((size_t)wn * Op::EB);
-    if (!wpacked) return fail(nullptr, TAMF_ERR_NOMEM, "hipMalloc failed");
-    hipLaunchKernelGGL((rowblock_pack_kernel<Op>), grid1d(wn * Op::EB / 16), dim3(256), 0, st, w, K, K, wpacked);
-  }
-#endif
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, "event");
   hipError_t e = hipSuccess;
   for (int it = -2; it < iters && e == hipSuccess; ++it) {
     if (it == 0) (void)hipEventRecord(e0, st);
     if (epi_kind == 2) {
-      EpiLN<Op> ep{vec, x, vec + N, vec + 2 * N, x, o, 1e-5f};
-      e = gemm_ln<Op>(ga, ep, st, wpacked);
+      e = hipErrorInvalidValue;  // (rounds 2 - 5: the LayerNorm-fused 64 x d tile; gone - kind 12 is the residual GEMM now)
     } else if (epi_kind == 3) {
       EpiStoreF32 ep{vec, x, N, ACT_NONE};
       if (M % 208 == 0 && ClipLaunch<Op, 2, EpiStoreF32>::applies(M / 208, 208, N, K))

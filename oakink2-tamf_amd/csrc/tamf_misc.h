@@ -70,60 +70,6 @@ __global__ void refine_in_kernel(const float* __restrict__ x_in, const float* __
   Op::range_flag(am, status);
 }
 
-// y = LayerNorm(resid + c) * gamma + beta, one wave per row of D = 64 * VPL columns; writes fp32 + operand
-// (second half of the two-kernel form of a LayerNorm-fused GEMM: tamf_hip.hip, FFN2)
-template <class Op, int VPL>
-__global__ void residual_ln_kernel(const float* __restrict__ c, const float* resid, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* xout, typename Op::elem_t* xop, int M,
-                                   float eps, unsigned* status) {
-  constexpr int D = 64 * VPL;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int c0 = lane * VPL;
-  float v[VPL];
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    v[j] = c[(long)row * D + c0 + j] + resid[(long)row * D + c0 + j];
-    s += v[j];
-  }
-  float mean, var;
-  if constexpr (VPL == 8) {  // 512 columns: the association order shared with the clip-tile LayerNorm (ln_row_sum512)
-#pragma clang fp contract(off)
-    mean = ln_row_sum512(v) * (1.0f / D);
-    float dq[VPL];
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const float dl = v[j] - mean;
-      dq[j] = dl * dl;
-    }
-    var = ln_row_sum512(dq) * (1.0f / D);
-  } else {
-    mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const float dl = v[j] - mean;
-      q += dl * dl;
-    }
-    var = wave_sum(q) * (1.0f / D);
-  }
-  const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) v[j] = fmaf((v[j] - mean) * rstd, gamma[c0 + j], beta[c0 + j]);  // (explicit: the same in every LayerNorm)
-  if constexpr (VPL % 4 == 0) {
-#pragma unroll
-    for (int j = 0; j < VPL; j += 4) gst16f(xout + (long)row * D + c0 + j, v[j], v[j + 1], v[j + 2], v[j + 3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) xout[(long)row * D + c0 + j] = v[j];
-  }
-  float am = 0.f;
-  if (xop) Op::template store_rc<VPL>(xop, (long)row * D + c0, v, am);  // (null in f32: xout is the operand)
-  Op::range_flag(am, status);
-}
-
 // current timestep of every clip; clamped to the rows of the timestep-embedding table (the host wrapper raises on an
 // out-of-range t like the reference's pe[timesteps] does - the clamp only keeps an unchecked caller in bounds)
 __global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, int B, int n_t) {

@@ -78,7 +78,7 @@ def lib() -> ctypes.CDLL:
         if hasattr(L, "tamf_refine_profile"):
             L.tamf_refine_profile.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
-        L.tamf_test_gemm_ln.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
+        L.tamf_test_gemm_resid.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
         L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
         L.tamf_test_philox.argtypes = [c_uint64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
         if hasattr(L, "tamf_bench_mfma_rate"):
@@ -405,15 +405,29 @@ def test_gemm(precision: str, a: torch.Tensor, w: torch.Tensor, bias: Optional[t
     return c
 
 
-def test_gemm_ln(precision: str, a, w, bias, resid, gamma, beta) -> torch.Tensor:
+def block_stats(x: torch.Tensor) -> torch.Tensor:
+    """(S_b, Q_b) of every 32-column block of every row of x (M, N): sum, and sum of squares about the block's own mean -> (M, N / 32, 2)"""
+    M, N = x.shape
+    b = x.double().reshape(M, N // 32, 32)
+    S = b.sum(-1)
+    Q = ((b - S[..., None] / 32.0) ** 2).sum(-1)
+    return torch.stack([S, Q], -1).float()
+
+
+def test_gemm_resid(precision: str, a, w, bb, gamma, x, stats_in=None):
+    """tamf_test_gemm_resid: returns (x_next (M, N), stats_out (M, N / 32, 2)); x is not modified"""
     dev = require_gpu(a.device)
     M, K = a.shape
     N = w.shape[0]
-    y = torch.empty((M, N), device=dev, dtype=torch.float32)
-    ts = [_dev_f32(t, dev) for t in (a, w, bias, resid, gamma, beta)]
-    _check(lib().tamf_test_gemm_ln(PRECISIONS[precision], M, N, K, *[c_void_p(t.data_ptr()) for t in ts],
-                                   c_void_p(y.data_ptr()), c_void_p(_stream_ptr(dev))))
-    return y
+    a, w, bb, gamma = [_dev_f32(t, dev) for t in (a, w, bb, gamma)]
+    y = _dev_f32(x, dev).clone()
+    st_in = _dev_f32(stats_in, dev) if stats_in is not None else None
+    st_out = torch.empty((M, N // 32, 2), device=dev, dtype=torch.float32)
+    _check(lib().tamf_test_gemm_resid(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
+                                      c_void_p(bb.data_ptr()), c_void_p(gamma.data_ptr()),
+                                      c_void_p(st_in.data_ptr() if st_in is not None else 0), c_void_p(y.data_ptr()),
+                                      c_void_p(st_out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    return y, st_out
 
 
 def test_attention(precision: str, qkv: torch.Tensor, H: int) -> torch.Tensor:

@@ -153,22 +153,24 @@ def test_gemm_bench_shapes(prec, N, K):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("K", [512, 2048])
-def test_gemm_ln_bench_shapes(prec, K):
+def test_gemm_resid_bench_shapes(prec, K):
+    """the residual GEMMs (out-proj K = 512, FFN2 K = 2048) at the bench shape, on the whole-clip tiles, with the LayerNorm of the residual deferred"""
     from oakink2_tamf_amd import hip_backend as hb
 
     M, N = 13312, 512
     g = torch.Generator().manual_seed(2)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
-    b = torch.randn(N, generator=g) * 0.1
-    r = torch.randn(M, N, generator=g)
+    bb = torch.randn(N, generator=g) * 0.1
+    u = torch.randn(M, N, generator=g) * 2.0 + 0.7
     ga = 1 + 0.1 * torch.randn(N, generator=g)
-    be = 0.1 * torch.randn(N, generator=g)
-    v = (a.double() @ w.double().t() + b.double()) + r.double()
-    ref = torch.nn.functional.layer_norm(v, (N,), ga.double(), be.double(), 1e-5)
-    got = hb.test_gemm_ln(prec, a.cuda(), w.cuda(), b.cuda(), r.cuda(), ga.cuda(), be.cuda()).double().cpu()
+    ref = (torch.nn.functional.layer_norm(u.double(), (N,), ga.double(), None, 1e-5) + bb.double()) + a.double() @ w.double().t()
+    got, st = hb.test_gemm_resid(prec, a.cuda(), w.cuda(), bb.cuda(), ga.cuda(), u.cuda(), hb.block_stats(u).cuda())
+    got = got.double().cpu()
     rel = float((got - ref).abs().max() / ref.abs().max())
     assert rel < GEMM_TOL[prec], (prec, K, rel)
+    want = hb.block_stats(got.float())
+    assert torch.allclose(st.cpu(), want, rtol=1e-4, atol=1e-3)
 
 
 REFINE_TOL = {"f32": 3e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 1e-1}
@@ -421,14 +423,10 @@ def test_modes_agree_on_random_shapes():
 # selection overrides of tamf_set_gemm_tuning (bits 20..): every alternative kernel of a launch must give the SAME BITS as the default
 # one - that is what makes a clip's sample independent of the batch it is in (different batch sizes select different kernels)
 SELECTIONS = {
-    0x001: "no clip tiles at all (128 x 128 / LayerNorm-fused tiles everywhere)",
+    0x001: "no clip tiles at all (128 x 128 tiles everywhere)",
     0x002: "FFN2 / out-proj not on clip tiles",
     0x008: "FFN1 on the 128 x 128 tiles",
-    0x010: "out-proj as clip GEMM + LayerNorm kernel",
-    0x020: "FFN1 on 128-column clip tiles",
-    0x040: "QKV on the 128 x 128 tiles (f32 default: clip tiles)",
-    0x080: "QKV as two clip launches (Q|K, V transposed)",
-    0x100: "FFN2 as clip GEMM + LayerNorm kernel (bf16 default: fused)",
+    0x040: "QKV on the 128 x 128 tiles (f32 default: clip tiles, Q|K and V transposed)",
     0x400: "clip tiles from 50 % utilisation",
 }
 
@@ -568,34 +566,6 @@ def test_gemm_clip_tiles_exact_integers_t160(prec, clips):
     got = hb.test_gemm(prec, a.cuda(), w.cuda(), b.cuda(), 0).cpu()
     ref = (a.long() @ w.long().t() + b.long()).float()
     assert torch.equal(got, ref), (prec, clips, int((got != ref).sum()))
-
-
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("B,T", [(64, 196), (32, 196), (48, 160)])
-def test_rowblock_ln_kernels_give_the_same_bits(full, full160, prec, B, T):
-    """The row-block LayerNorm GEMMs of round 4 (csrc/tamf_gemm_rowblock.h: weights streamed L2 -> registers from a fragment-major
-    copy, early / late waves, LayerNorm sums in the ln_row_sum512 tree) are an A/B selection (tuning word 0x7FFFF, set before the weights
-    are finalised; not faster, so off by default): same bits as the default kernels at 64 / 48 / 32 rows per workgroup."""
-    from oakink2_tamf_amd.hip_backend import lib
-
-    fx = full if T == T_FULL else full160
-    cond, x, t = _sub(fx["cond"], slice(0, B)), fx["x"][:B], fx["t"][:B]
-    ctx = _make_ctx(fx["arch"], fx["sd"], B, T, prec)
-    _set_cond(ctx, cond)
-    ref = ctx.denoise(x, t).cpu()
-    n_default = ctx.step_kernel_count
-    ctx.close()
-    try:
-        lib().tamf_set_gemm_tuning(0x7FFFF)
-        ctx = _make_ctx(fx["arch"], fx["sd"], B, T, prec)
-        _set_cond(ctx, cond)
-        got = ctx.denoise(x, t).cpu()
-        n_rb = ctx.step_kernel_count
-        ctx.close()
-    finally:
-        lib().tamf_set_gemm_tuning(-1)
-    assert torch.equal(got, ref), (prec, B, T, float((got - ref).abs().max()))
-    assert n_rb <= n_default, (n_rb, n_default)  # (round 5: the 16-bit modes run the deferred-LayerNorm form, which has no LayerNorm GEMM to replace)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])

@@ -56,20 +56,31 @@ def test_gemm_asymmetric_identity(hb, prec):
     assert torch.equal(got, w.t().contiguous())
 
 
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("M,N,K", [(200, 128, 128), (333, 256, 1024), (130, 512, 512), (64, 512, 2048), (512, 512, 512), (1000, 512, 1024)])
-def test_gemm_residual_layernorm(hb, prec, M, N, K):
-    g = torch.Generator().manual_seed(2)
+def _resid_case(M, N, K, seed, with_ln, dc=0.0):
+    g = torch.Generator().manual_seed(seed)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
-    b = torch.randn(N, generator=g) * 0.1
-    r = torch.randn(M, N, generator=g)
-    ga = 1 + 0.1 * torch.randn(N, generator=g)
-    be = 0.1 * torch.randn(N, generator=g)
-    v = (a.double() @ w.double().t() + b.double()) + r.double()
-    ref = torch.nn.functional.layer_norm(v, (N,), ga.double(), be.double(), 1e-5)
-    got = hb.test_gemm_ln(prec, a.cuda(), w.cuda(), b.cuda(), r.cuda(), ga.cuda(), be.cuda())
+    bb = torch.randn(N, generator=g) * 0.1
+    u = torch.randn(M, N, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + dc * torch.randn(M, 1, generator=g)
+    ga = 1 + 0.3 * torch.randn(N, generator=g) if with_ln else torch.ones(N)
+    y = torch.nn.functional.layer_norm(u.double(), (N,), ga.double(), None, 1e-5) if with_ln else u.double()
+    ref = (y + bb.double()) + a.double() @ w.double().t()
+    return a, w, bb, ga, u, ref
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("with_ln", [True, False])
+@pytest.mark.parametrize("M,N,K", [(200, 128, 128), (333, 256, 1024), (130, 512, 512), (64, 512, 2048), (512, 512, 512), (1000, 512, 1024),
+                                   (3 * 208, 512, 512), (2 * 168, 512, 2048)])
+def test_gemm_residual_with_deferred_layernorm(hb, prec, with_ln, M, N, K):
+    """EpiResid through tamf_test_gemm_resid: the residual add of an encoder sublayer with the LayerNorm of its input applied on the way
+    (reference: x + sublayer(x) behind norm1 / norm2, interaction_segment_mdm.py:63-70), and the block statistics it leaves"""
+    a, w, bb, ga, u, ref = _resid_case(M, N, K, 2, with_ln, dc=1.5)
+    got, st = hb.test_gemm_resid(prec, a.cuda(), w.cuda(), bb.cuda(), ga.cuda(), u.cuda(), hb.block_stats(u).cuda() if with_ln else None)
     assert _rel(got, ref) < TOL[prec]
+    want = hb.block_stats(got.cpu())  # the statistics describe the row that was STORED (fp32)
+    assert torch.allclose(st.cpu()[..., 0], want[..., 0], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(st.cpu()[..., 1], want[..., 1], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("prec", PRECS)

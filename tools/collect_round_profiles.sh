@@ -32,15 +32,12 @@ import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.getcwd())
 out, dt = sys.argv[1:3]
 CLASSES = [("EpiQKV", "gemm_qkv"), ("EpiQK<", "gemm_qk"), ("EpiVt", "gemm_v"), ("attn_", "attention"), ("EpiBiasAct", "gemm_ffn1_gelu"),
-           ("EpiResid", "pair:gemm_outproj:gemm_ffn2"),     # 16-bit modes (deferred LayerNorm): out-proj and FFN2 alternate, layer by layer
-           ("EpiStoreF32", "pair:gemm_outproj:gemm_ffn2"),  # f32: the same two GEMMs in front of their LayerNorm kernels
-           ("residual_ln_kernel", "pair:outproj_residual_ln:ffn2_residual_ln"), ("EpiLN<", "gemm_ln"), ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
-SPLIT = dt in ("bf16x3", "f16x3")  # split modes: every EpiLN launch is the out-proj; the others alternate out-proj / FFN2 per layer
+           ("EpiResid", "pair:gemm_outproj:gemm_ffn2"),     # the residual GEMMs (deferred LayerNorm): out-proj and FFN2 alternate, layer by layer
+           ("EpiSeqRows", "gemm_input_merge2"), ("EpiHead", "gemm_head_ddpm")]
 def per_launch(ctr):
     f = glob.glob(f"{out}/pmc_{dt}_{ctr}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
-    ln_seen = {}
     pair_seen = collections.defaultdict(dict)
     for r in rows:
         for pat, name in CLASSES:
@@ -50,10 +47,6 @@ def per_launch(ctr):
                     if r["Dispatch_Id"] not in seen:
                         seen[r["Dispatch_Id"]] = len(seen)
                     name = name.split(":")[1 + seen[r["Dispatch_Id"]] % 2]
-                if name == "gemm_ln":
-                    if r["Dispatch_Id"] not in ln_seen:
-                        ln_seen[r["Dispatch_Id"]] = len(ln_seen)
-                    name = "gemm_outproj_ln" if (SPLIT or ln_seen[r["Dispatch_Id"]] % 2 == 0) else "gemm_ffn2_ln"
                 acc[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
                 break
     return {k: sorted(v.values())[len(v) // 2] for k, v in acc.items()}  # median over launches (merge0's BiasAct launch is the minority)

@@ -22,23 +22,23 @@ def algorithmic_bytes(kernel, mode, B, T, d=512, ff=2048, P=5):
     M, eb = B * Sp, EB[mode]
     act = lambda cols: M * cols * eb       # an operand matrix of M rows
     f32 = lambda cols: M * cols * 4
-    deferred = mode != "f32"
+    opw = lambda cols: 0 if mode == "f32" else act(cols)  # a separate operand copy of an fp32 result (f32: the fp32 buffer IS the operand)
     t = {
         "gemm_qkv": act(d) + 3 * d * d * eb + act(3 * d),
         "gemm_qk": act(d) + 2 * d * d * eb + act(2 * d),
         "gemm_v": act(d) + d * d * eb + act(d),
         "attention": act(3 * d) + act(d),
         "gemm_ffn1_gelu": act(d) + ff * d * eb + act(ff),
-        # residual GEMMs: 16-bit (deferred LayerNorm): operand in, weight, residual fp32 in and out, operand out; f32: operand in, weight, fp32 product out
-        "gemm_outproj": act(d) + d * d * eb + (2 * f32(d) + act(d) if deferred else f32(d)),
-        "gemm_ffn2": act(ff) + d * ff * eb + (2 * f32(d) + act(d) if deferred else f32(d)),
-        "outproj_residual_ln": 3 * f32(d),  # f32: product + residual in, state out (= the operand)
+        # residual GEMMs (deferred LayerNorm): operand in, weight, residual fp32 in and out, operand out (16-bit modes)
+        "gemm_outproj": act(d) + d * d * eb + 2 * f32(d) + opw(d),
+        "gemm_ffn2": act(ff) + d * ff * eb + 2 * f32(d) + opw(d),
+        "outproj_residual_ln": 3 * f32(d),  # (rounds 2 - 4, f32 until round 5: product + residual in, state out)
         "ffn2_residual_ln": 3 * f32(d),
         "gemm_outproj_ln": act(d) + d * d * eb + 2 * f32(d) + act(d),
         "gemm_ffn2_ln": act(ff) + d * ff * eb + 2 * f32(d) + act(d),
         "gemm_input_merge0": B * T * (128 * eb + d * 4 + d * eb) + d * 128 * eb,
-        "gemm_input_merge2": B * T * d * eb + d * d * eb + f32(d) + (act(d) if deferred else 0),
-        "gemm_head_ddpm": act(d) + 128 * d * eb + B * T * 128 * (4 + 4 + (eb if deferred else 0)),
+        "gemm_input_merge2": B * T * d * eb + d * d * eb + f32(d) + opw(d),
+        "gemm_head_ddpm": act(d) + 128 * d * eb + B * T * 128 * (4 + 4 + (0 if mode == "f32" else eb)),
     }
     return t.get(kernel)
 

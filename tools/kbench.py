@@ -16,8 +16,8 @@ def bench(prec, epi, krot, M, N, K, iters=20):
 if __name__ == "__main__":
     torch.cuda.init(); torch.zeros(1, device="cuda")
     M = 13312
-    shapes = [("qkv", 1, M, 1536, 512), ("ffn1", 0, M, 2048, 512), ("outproj_ln", 2, M, 512, 512), ("ffn2_ln", 2, M, 512, 2048), ("ffn2", 3, M, 512, 2048),
-              ("qkv_ln", 11, M, 1536, 512), ("ffn1_ln", 10, M, 2048, 512), ("outproj_res", 12, M, 512, 512), ("ffn2_res", 12, M, 512, 2048)]  # deferred-LayerNorm forms (16-bit modes)
+    shapes = [("qkv", 1, M, 1536, 512), ("ffn1", 0, M, 2048, 512), ("ffn2_plain", 3, M, 512, 2048),
+              ("qkv_ln", 11, M, 1536, 512), ("ffn1_ln", 10, M, 2048, 512), ("outproj_res", 12, M, 512, 512), ("ffn2_res", 12, M, 512, 2048)]  # the forms of the step (deferred LayerNorm)
     precs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bf16x3", "bf16", "f32"]
     variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1]
     for prec in precs:

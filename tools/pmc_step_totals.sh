@@ -20,7 +20,7 @@ if not f:
 tot = collections.defaultdict(float); attn = set()
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]
-    if not any(s in k for s in ("gemm_kernel", "clip_gemm_kernel", "attn_", "residual_ln_kernel", "rowblock_")): continue
+    if not any(s in k for s in ("gemm_kernel", "clip_gemm_kernel", "attn_")): continue
     if "OpF32" in k and "gemm_kernel<OpF32" in k and sys.argv[1] and False: continue
     tot[r["Counter_Name"]] += float(r["Counter_Value"])
     if "attn_" in k: attn.add(r["Dispatch_Id"])
