@@ -268,9 +268,10 @@ int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t 
 
 /* ---- kernel benchmarks / tuning (tools/kbench.py) ------------------------------------------------ */
 /* Average milliseconds of `iters` launches of one GEMM on random operands already resident in HBM.
- * epi_kind: 0 = 128x128 tile, bias + GELU (FFN1 shape); 1 = 128x128 tile, QKV epilogue (N = 3d);
- * 2 = 64xN tile, residual + LayerNorm; 3 = 128x128 tile, bias, fp32 output (FFN2 of the two-kernel form).  krot: -1 = default tuning, >= 0 = GemmArgs::krot bits (csrc/tamf_gemm.h:
- * K-loop rotation, L2 touch-prefetch distance, ablation flags). */
+ * epi_kind: 0 = bias + GELU (FFN1 shape; clip tiles when M is a multiple of 208); 1 = 128x128 tile, QKV epilogue (N = 3d);
+ * 3 = bias, fp32 output; the forms the step runs (deferred LayerNorm, csrc/tamf_device.h): 10 = FFN1 with the row factors,
+ * 11 = QKV with the row factors, 12 = residual GEMM (EpiResid).  (2 = the LayerNorm-fused 64xN tile of rounds 1 - 5: gone, invalid.)
+ * krot: -1 = default tuning, >= 0 = GemmArgs::krot bits (csrc/tamf_gemm.h: K-loop rotation, L2 touch-prefetch distance, ablation flags). */
 int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                     int32_t iters, float* ms_out, void* stream);
 /* Average milliseconds of `iters` launches of the attention kernel alone on random Q | K / V^T operands resident in HBM (B clips,
