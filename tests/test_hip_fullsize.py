@@ -306,7 +306,7 @@ def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name):
 @pytest.mark.parametrize("T", [196, 160])
 def test_kernel_choice_over_batch_sizes(prec, T):
     """The launch rules switch kernels with the batch size (clip tiles from 74 % fill, row-part tiles up to half the CUs, query splits of the
-    attention, 64-row tiles for short-K GEMMs, two-kernel LayerNorm forms for under-filled tiles): at 24 batch sizes from 1 to 128 the default
+    attention, 64-row tiles for short-K GEMMs, row-part tiles of the residual GEMMs at 32 clips or fewer): at 24 batch sizes from 1 to 128 the default
     kernels against selection 1 (no clip tiles anywhere) - the same bits - and clip 0 of every batch against clip 0 alone."""
     from oracle import mdm_oracle as O
     from oakink2_tamf_amd.hip_backend import lib
