@@ -516,6 +516,7 @@ def main_refine(args, dev, ptrace):
                 "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": None,
                 "avg_launch_ms": dom["avg_ms"], "share_of_step": dom["share"], "forward_algorithmic_gflop": head["forward_gflop"],
                 "launches_per_forward": sum(r["launches_per_forward"] for r in head["profile"]),
+                "kernels": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in head["profile"]],
                 "note": "a 1.2-ms forward of 50 launches over 12 736 token rows of width 256: launch ramps and epilogues, not a roofline, bound it (SURVEY.md 8d)"}
     check = {args.dtype: head["err"]} if head["err"] is not None else {}
     finite_by, range_flags = {args.dtype: head["finite"]}, ({args.dtype: head["flag"]} if args.dtype == "f16x3" else {})

@@ -97,18 +97,19 @@ struct tamf_ctx {
   // weights
   std::vector<LayerW> layers;
   OperandBuf Wfused, Wm2, Wf;
-  float *bm2 = nullptr, *bf = nullptr, *cbias = nullptr;
+  float *bm2 = nullptr, *bf = nullptr;
   float* pe = nullptr;    // [5000][d]
   float* temb = nullptr;  // [n_t][d]
-  OperandBuf Wm1b_f32, Wt1_f32, Wt2_f32;
+  OperandBuf Wt1_f32, Wt2_f32;
   float *bt1 = nullptr, *bt2 = nullptr;
-  float *Wtxt = nullptr, *btxt = nullptr, *Wshape = nullptr, *bshape = nullptr, *Wobj = nullptr, *bobj = nullptr;
-  float *Wq = nullptr, *bq = nullptr, *rh = nullptr, *lh = nullptr;
+  // conditioning (tamf_misc.h, prefix_rows_kernel / cobj_kernel): transposed weights W^T [K][d]; WcT / bc = input_merge.0[:, d:2d] composed with
+  // obj_input_process.poseEmbedding (and the fused bias of input_merge.0)
+  float *WtxtT = nullptr, *btxt = nullptr, *WshapeT = nullptr, *bshape = nullptr, *WobjT = nullptr, *bobj = nullptr;
+  float *WcT = nullptr, *bc = nullptr, *rh = nullptr, *lh = nullptr;
   // activations
   int B = 0, T = 0, S = 0, Sp = 0, Skp = 0, M = 0;
   long Mmax = 0;
-  float *xs = nullptr, *cobj = nullptr, *X = nullptr, *pstatic = nullptr, *etmp = nullptr, *meanbuf = nullptr,
-        *objfeat = nullptr;
+  float *xs = nullptr, *cobj = nullptr, *X = nullptr, *pstatic = nullptr;
   OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
   // f32: an fp32 operand matrix [rows][ld] is byte for byte the fp32 tensor, so the residual stream X and the sampler state xs ARE
   // their own operands (X_op.p = X, xs_op.p = xs) and the kernels that used to write both copies write one (X_st / xs_st = null):
@@ -653,11 +654,6 @@ static int alloc_workspaces(tamf_ctx* ctx, int max_batch, int max_frames) {
   A(alloc_operand(ctx, &ctx->A_op, Mmax * d, true));
   A(alloc_operand(ctx, &ctx->H_op, Mmax * ctx->ff, true));
   A(dev_alloc(ctx, (void**)&ctx->pstatic, (long)max_batch * ctx->P * d * 4, true));
-  A(dev_alloc(ctx, (void**)&ctx->etmp, (long)max_batch * d * 4));
-  const long meansz = std::max<long>((long)max_batch * std::max(ctx->arch.obj_embed_dim, ctx->arch.hand_shape_dim),
-                                     BT * ctx->arch.obj_input_dim);
-  A(dev_alloc(ctx, (void**)&ctx->meanbuf, meansz * 4));
-  A(dev_alloc(ctx, (void**)&ctx->objfeat, BT * d * 4));
   A(dev_alloc(ctx, (void**)&ctx->tcur, (long)max_batch * 4, true));
   A(dev_alloc(ctx, (void**)&ctx->status, 16, true));
   A(dev_alloc(ctx, (void**)&ctx->side_dev, max_batch, true));
@@ -779,7 +775,7 @@ extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_fra
   for (void* p : ctx->ws_allocs) (void)hipFree(p);
   ctx->ws_allocs.clear();
   ctx->guards.erase(std::remove_if(ctx->guards.begin(), ctx->guards.end(), [](const GuardRec& g) { return g.ws; }), ctx->guards.end());
-  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = ctx->etmp = ctx->meanbuf = ctx->objfeat = nullptr;
+  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = nullptr;
   ctx->xs_op = ctx->h1_op = ctx->X_op = ctx->QK_op = ctx->Vt_op = ctx->A_op = ctx->H_op = OperandBuf{};
   ctx->X_st = ctx->xs_st = nullptr;
   ctx->stat_att = ctx->stat_ffn = nullptr;
@@ -923,7 +919,10 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     const float* bm1 = R("input_merge.0.bias");
     const float* Wp = R("input_process.poseEmbedding.weight");
     const float* bp = R("input_process.poseEmbedding.bias");
-    std::vector<float> fused((size_t)d * ctx->XK, 0.f), cb(d), wm1b((size_t)d * d);
+    const int qd = ctx->arch.obj_input_dim;
+    const float* Wq = R("obj_input_process.poseEmbedding.weight");
+    const float* bq = R("obj_input_process.poseEmbedding.bias");
+    std::vector<float> fused((size_t)d * ctx->XK, 0.f), cb(d), wct((size_t)qd * d);
     for (int n = 0; n < d; ++n) {
       double acc_b = bm1[n];
       for (int j = 0; j < d; ++j) acc_b += (double)Wm1[(size_t)n * mk + j] * bp[j];
@@ -932,7 +931,13 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
         for (int j = 0; j < d; ++j) a += (double)Wm1[(size_t)n * mk + j] * Wp[(size_t)j * F + k];
         fused[(size_t)n * ctx->XK + k] = (float)a;
       }
-      for (int j = 0; j < d; ++j) wm1b[(size_t)n * d + j] = Wm1[(size_t)n * mk + d + j];
+      // the object half, hoisted out of the loop (cobj_kernel): W_m1[:, d:2d] . (W_q m + b_q) = Wc m + ..., Wc = W_m1[:, d:2d] . W_q
+      for (int k = 0; k < qd; ++k) {
+        double a = 0;
+        for (int j = 0; j < d; ++j) a += (double)Wm1[(size_t)n * mk + d + j] * Wq[(size_t)j * qd + k];
+        wct[(size_t)k * d + n] = (float)a;
+      }
+      for (int j = 0; j < d; ++j) acc_b += (double)Wm1[(size_t)n * mk + d + j] * bq[j];
       if (isR) {
         const int Hd = ctx->arch.h2o_dim;
         const float* Wh = R("h2o_dist_input_process.poseEmbedding.weight");
@@ -947,8 +952,8 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
       cb[n] = (float)acc_b;
     }
     TRY(upload_operand(ctx, prec, fused.data(), d, ctx->XK, ctx->XK, &ctx->Wfused, "input_merge.0.weight x poseEmbedding.weight (fused)"));
-    TRY(upload_operand(ctx, TAMF_PREC_F32, wm1b.data(), d, d, d, &ctx->Wm1b_f32, "input_merge.0.weight"));
-    TRY(dev_upload(ctx, &ctx->cbias, cb.data(), cb.size()));
+    TRY(dev_upload(ctx, &ctx->WcT, wct.data(), wct.size()));
+    TRY(dev_upload(ctx, &ctx->bc, cb.data(), cb.size()));
   }
   TRY(upload_operand(ctx, prec, R("input_merge.2.weight"), d, d, d, &ctx->Wm2, "input_merge.2.weight"));
   TRY(upload_f32(ctx, "input_merge.2.bias", &ctx->bm2));
@@ -973,16 +978,23 @@ extern "C" int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void*
     TRY(dev_upload(ctx, &ctx->bf, bfp.data(), bfp.size()));
   }
   TRY(upload_f32(ctx, "sequence_pos_encoder.pe", &ctx->pe));
-  TRY(upload_f32(ctx, "hand_shape_process.shape_embed.weight", &ctx->Wshape));
+  auto upload_T = [&](const std::string& name, int N, int K, float** p) -> int {  // W [N][K] -> W^T [K][N] (prefix_rows_kernel)
+    const float* W = R(name);
+    std::vector<float> t((size_t)N * K);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = W[(size_t)n * K + k];
+    return dev_upload(ctx, p, t.data(), t.size());
+  };
+  if (ctx->arch.hand_shape_dim > 64 || ctx->arch.obj_input_dim > COBJ_QMAX || d > 1024)
+    return fail(ctx, TAMF_ERR_INVALID, "hand_shape_dim > 64, obj_input_dim > 16 or latent_dim > 1024");
+  TRY(upload_T("hand_shape_process.shape_embed.weight", d, ctx->arch.hand_shape_dim, &ctx->WshapeT));
   TRY(upload_f32(ctx, "hand_shape_process.shape_embed.bias", &ctx->bshape));
-  TRY(upload_f32(ctx, "obj_embed_process.embedding.weight", &ctx->Wobj));
+  TRY(upload_T("obj_embed_process.embedding.weight", d, ctx->arch.obj_embed_dim, &ctx->WobjT));
   TRY(upload_f32(ctx, "obj_embed_process.embedding.bias", &ctx->bobj));
-  TRY(upload_f32(ctx, "obj_input_process.poseEmbedding.weight", &ctx->Wq));
-  TRY(upload_f32(ctx, "obj_input_process.poseEmbedding.bias", &ctx->bq));
   TRY(upload_f32(ctx, "hand_side_process.rh_embed", &ctx->rh));
   TRY(upload_f32(ctx, "hand_side_process.lh_embed", &ctx->lh));
   if (ctx->has_t) {
-    TRY(upload_f32(ctx, "embed_text.weight", &ctx->Wtxt));
+    TRY(upload_T("embed_text.weight", d, ctx->arch.clip_dim, &ctx->WtxtT));
     TRY(upload_f32(ctx, "embed_text.bias", &ctx->btxt));
     TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.0.weight"), d, d, d, &ctx->Wt1_f32, "embed_timestep.time_embed.0.weight"));
     TRY(upload_operand(ctx, TAMF_PREC_F32, R("embed_timestep.time_embed.2.weight"), d, d, d, &ctx->Wt2_f32, "embed_timestep.time_embed.2.weight"));
@@ -1087,40 +1099,20 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
   ctx->Skp = vt_row_keys(ctx->S, ctx->Sp);
   ctx->M = B * ctx->Sp;
   ctx->cond_set = false;
-  int j = 0;
-  if (ht) {
-    hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, text_emb_dev, ctx->Wtxt, ctx->btxt,
-                       ctx->etmp, (long)B, d, ctx->arch.clip_dim);
-    hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d,
-                       nrows, j, ht + j);
-    ++j;
-  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->side_dev, hand_side_host, B, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(hand_side_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->side_dev, ctx->rh, ctx->lh, ctx->etmp, B, d);
-  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
-                     j, ht + j);
-  ++j;
-  const int sd = ctx->arch.hand_shape_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * sd), dim3(256), 0, st, shape_dev, ctx->meanbuf, B, T, sd, (const int*)nullptr);
-  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wshape, ctx->bshape,
-                     ctx->etmp, (long)B, d, sd);
-  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
-                     j, ht + j);
-  ++j;
-  const int od = ctx->arch.obj_embed_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * od), dim3(256), 0, st, obj_emb_dev, ctx->meanbuf, B, nobj, od, cnt);
-  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wobj, ctx->bobj,
-                     ctx->etmp, (long)B, d, od);
-  hipLaunchKernelGGL(prefix_pack_kernel, grid1d((long)B * d), dim3(256), 0, st, ctx->etmp, ctx->pstatic, ctx->pe, B, d, nrows,
-                     j, ht + j);
-  // object half of input_merge.0, hoisted: cobj[b,tau,:] = W_m1[:, d:2d] (W_q mean_o traj + b_q) + fused bias
-  const int qd = ctx->arch.obj_input_dim;
-  hipLaunchKernelGGL(mean_mid_kernel, grid1d((long)B * T * qd), dim3(256), 0, st, obj_traj_dev, ctx->meanbuf, B, nobj, T * qd, cnt);
-  hipLaunchKernelGGL(linear_small_kernel, grid1d((long)B * T * d), dim3(256), 0, st, ctx->meanbuf, ctx->Wq, ctx->bq,
-                     ctx->objfeat, (long)B * T, d, qd);
-  GemmArgs<OpF32> ga{ctx->objfeat, d, (const float*)ctx->Wm1b_f32.p, d, B * T, d, d, 0};
-  EpiBiasAct<OpF32> ep{ctx->cbias, nullptr, 0, ctx->cobj, d, ACT_NONE};
-  HIPCHK(ctx, gemm128<OpF32>(ga, ep, st));
+  // two launches (tamf_misc.h): the static prefix rows of every clip, and the hoisted object half of input_merge.0 per frame
+  const int sd = ctx->arch.hand_shape_dim, od = ctx->arch.obj_embed_dim, qd = ctx->arch.obj_input_dim, cd = ht ? ctx->arch.clip_dim : 0;
+  PrefixArgs pa{};
+  pa.text = ht ? text_emb_dev : nullptr; pa.WtxtT = ctx->WtxtT; pa.btxt = ctx->btxt;
+  pa.side = ctx->side_dev; pa.rh = ctx->rh; pa.lh = ctx->lh;
+  pa.shape = shape_dev; pa.WshapeT = ctx->WshapeT; pa.bshape = ctx->bshape;
+  pa.oemb = obj_emb_dev; pa.WobjT = ctx->WobjT; pa.bobj = ctx->bobj; pa.cnt = cnt;
+  pa.pe = ctx->pe; pa.pstatic = ctx->pstatic;
+  pa.B = B; pa.d = d; pa.T = T; pa.sd = sd; pa.nobj = nobj; pa.od = od; pa.clip_dim = cd; pa.nrows = nrows; pa.ht = ht;
+  const size_t psm = (size_t)(std::max(std::max(cd, od), sd) + 1024) * sizeof(float);
+  hipLaunchKernelGGL(prefix_rows_kernel, dim3(B, nrows), dim3(1024), psm, st, pa);
+  hipLaunchKernelGGL(cobj_kernel, dim3((unsigned)(((long)B * T + COBJ_ROWS - 1) / COBJ_ROWS)), dim3(256), 0, st, obj_traj_dev, ctx->WcT, ctx->bc,
+                     ctx->cobj, B, nobj, T, qd, d, cnt);
   HIPCHK(ctx, hipGetLastError());
   ctx->cond_set = true;
   return 0;

@@ -142,51 +142,137 @@ __global__ void set_loop_params_kernel(LoopParams* lp, const float* noise, float
   }
 }
 
-// out[o][i] = mean_m in[o][m][i]   (torch.mean: sum / n); with `cnt` the mean of outer index o runs over its first
-// clamp(cnt[o], 1, nmid) middle entries only (per-clip object counts of a zero-padded batch, tamf_set_cond_ragged)
-__global__ void mean_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int outer, int nmid, int inner,
-                                const int* __restrict__ cnt) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)outer * inner) return;
-  const int i = (int)(idx % inner);
-  const long o = idx / inner;
-  const int n = cnt ? max(1, min(cnt[o], nmid)) : nmid;
+// ---------------------------------------------------------------------------------------------
+// Conditioning precompute (tamf_set_cond): everything of a clip that does not depend on the DDPM step, in TWO launches.
+// (Rounds 1 - 4 ran it as 12 - 14 launches of one-thread-per-output kernels - fine once per 1000-step loop, but the R trunk runs it
+// once per forward: 250 of its 1 366 us, of which 104 us a K = 768 linear with strided weight reads and 55 us a mean over T walked by
+// 640 threads; profiles/r05/config4_timeline_c21.txt.)
+//
+// (1) prefix_rows_kernel: block (b, j) computes static prefix row j of clip b - [text (G only),] hand side, hand shape, object embedding:
+//   text   W_txt . text_embedding[b] + b_txt                               embed_text, interaction_segment_mdm.py:73,146-147
+//   side   rh_embed | lh_embed                                             HandsideProcess :266-288
+//   shape  W_s . mean_T(betas[b]) + b_s       (mean over ALL T frames)     HandShapeProcess :291-303
+//   obj    W_o . mean_objects(obj_embedding[b]) + b_o                      ObjectEmbedProcess :251-263 (cnt: each clip's own object count)
+// then nan_to_num and + PE[row] (prefix assembly :157-159, PositionalEncoding :195-198).  The linear maps read a TRANSPOSED weight
+// (W^T [K][d]: consecutive threads read consecutive addresses), the input vector from LDS; sums run in a fixed order.
+struct PrefixArgs {
+  const float* text;   // [B][clip_dim] or null (R: no text / timestep rows)
+  const float *WtxtT, *btxt;
+  const unsigned char* side;  // [B] 0 = rh, 1 = lh
+  const float *rh, *lh;
+  const float* shape;  // [B][T][sd]
+  const float *WshapeT, *bshape;
+  const float* oemb;   // [B][nobj][od]
+  const float *WobjT, *bobj;
+  const int* cnt;      // [B] object counts or null (all nobj rows)
+  const float* pe;
+  float* pstatic;      // [B][nrows][d]
+  int B, d, T, sd, nobj, od, clip_dim, nrows, ht;
+};
+// NT = 1024 threads: thread (c, q) takes output column c and the q-th of Q = NT / d segments of K (one thread per output would walk
+// K = 768 weight rows one load latency at a time: 83 us); the Q partial sums of an output are added in order.
+__global__ __launch_bounds__(1024) void prefix_rows_kernel(const PrefixArgs a) {
+  extern __shared__ float sh[];  // [KMAX] input vector | [NT] partial sums (frame mean: [G][sd]; linear: [Q][d])
+  const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  const int kind = a.ht ? j : j + 1;  // 0 text, 1 side, 2 shape, 3 object embedding
+  const int KMAX = max(max(a.clip_dim, a.od), a.sd);
+  float* part = sh + KMAX;
+  const float *WT = nullptr, *bias = nullptr;
+  int K = 0;
+  if (kind == 0) {
+    for (int k = tid; k < a.clip_dim; k += NT) sh[k] = a.text[(long)b * a.clip_dim + k];
+    WT = a.WtxtT; bias = a.btxt; K = a.clip_dim;
+  } else if (kind == 2) {
+    // mean over the T frames: G = NT / sd groups of frames (t = g, g + G, ...), then the groups in order
+    const int sd = a.sd, G = min(NT / sd, a.T);
+    if (tid < G * sd) {
+      const int i = tid % sd, g = tid / sd;
+      float s = 0.f;
+      for (int t = g; t < a.T; t += G) s += a.shape[((long)b * a.T + t) * sd + i];
+      part[g * sd + i] = s;
+    }
+    __syncthreads();
+    if (tid < sd) {
+      float s = 0.f;
+      for (int g = 0; g < G; ++g) s += part[g * sd + tid];
+      sh[tid] = s / (float)a.T;
+    }
+    WT = a.WshapeT; bias = a.bshape; K = sd;
+  } else if (kind == 3) {
+    const int n = a.cnt ? max(1, min(a.cnt[b], a.nobj)) : a.nobj;
+    for (int k = tid; k < a.od; k += NT) {
+      float s = 0.f;
+      for (int m = 0; m < n; ++m) s += a.oemb[((long)b * a.nobj + m) * a.od + k];
+      sh[k] = s / (float)n;
+    }
+    WT = a.WobjT; bias = a.bobj; K = a.od;
+  }
+  __syncthreads();
+  const int d = a.d, Q = max(1, NT / d);  // (d <= NT: tamf_ctx_create limits the latent width to 512)
+  const int c = tid % d, q = tid / d;
   float s = 0.f;
-  for (int m = 0; m < n; ++m) s += in[(o * nmid + m) * inner + i];
-  out[idx] = s / (float)n;
+  if (kind != 1 && q < Q) {
+    const int seg = (K + Q - 1) / Q, k0 = q * seg, k1 = min(K, k0 + seg);
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s = fmaf(sh[k], WT[(long)k * d + c], s);
+    part[q * d + c] = s;
+  }
+  __syncthreads();
+  if (q == 0) {
+    float v;
+    if (kind == 1) {
+      v = a.side[b] ? a.lh[c] : a.rh[c];
+    } else {
+      v = part[c];
+      for (int qq = 1; qq < Q; ++qq) v += part[qq * d + c];
+      v += bias[c];
+    }
+    a.pstatic[((long)b * a.nrows + j) * d + c] = nan_to_num(v) + a.pe[(long)(a.ht + j) * d + c];
+  }
 }
 
-// out[r][n] = sum_k in[r][k] * W[n][k] + bias[n]  (tiny K; one thread per output)
-__global__ void linear_small_kernel(const float* __restrict__ in, const float* __restrict__ W,
-                                    const float* __restrict__ bias, float* __restrict__ out, long R, int N, int K) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * N) return;
-  const int n = (int)(idx % N);
-  const long r = idx / N;
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s = fmaf(in[r * K + k], W[(long)n * K + k], s);
-  out[idx] = s + (bias ? bias[n] : 0.f);
+// (2) cobj_kernel: the object half of input_merge.0, hoisted out of the DDPM loop - per frame
+//   cobj[b, t, :] = W_m1[:, d:2d] . (W_q . mean_objects(obj_traj[b, :, t, :]) + b_q) + (b_m1 + W_m1[:, :d] . b_p [+ R: W_m1[:, 2d:] . b_h])
+// (ObjectInputProcess :233-248 - Linear(9 -> d) per object, then the mean = the Linear of the mean - and input_merge :54-58,164-166).
+// The two linear maps are one: Wc = W_m1[:, d:2d] . W_q (d x 9) and bc, composed in float64 at tamf_finalize_weights; WcT = Wc^T [qd][d].
+// A block takes COBJ_ROWS frames: their 9-vectors of object means go through LDS, a thread keeps the 9 weights of its column(s) in
+// registers (one thread per output re-read 27 values per output: 43 us; this form is bound by its 12.8 MB of stores).
+constexpr int COBJ_ROWS = 32, COBJ_QMAX = 16;
+__global__ __launch_bounds__(256) void cobj_kernel(const float* __restrict__ traj, const float* __restrict__ WcT, const float* __restrict__ bc,
+                                                   float* __restrict__ cobj, int B, int nobj, int T, int qd, int d, const int* __restrict__ cnt) {
+  __shared__ float m[COBJ_ROWS][COBJ_QMAX];
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * COBJ_ROWS, rows_all = (long)B * T;
+  for (int e = tid; e < COBJ_ROWS * qd; e += blockDim.x) {
+    const int r = e / qd, k = e % qd;
+    const long bt = row0 + r;
+    float v = 0.f;
+    if (bt < rows_all) {
+      const int b = (int)(bt / T), t = (int)(bt % T);
+      const int n = cnt ? max(1, min(cnt[b], nobj)) : nobj;
+      float s = 0.f;
+      for (int o = 0; o < n; ++o) s += traj[(((long)b * nobj + o) * T + t) * qd + k];
+      v = s / (float)n;
+    }
+    m[r][k] = v;
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += blockDim.x) {
+    float w[COBJ_QMAX];
+#pragma unroll
+    for (int k = 0; k < COBJ_QMAX; ++k) w[k] = k < qd ? WcT[(long)k * d + c] : 0.f;
+    const float bias = bc[c];
+    for (int r = 0; r < COBJ_ROWS; ++r) {
+      if (row0 + r >= rows_all) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < COBJ_QMAX; ++k)
+        if (k < qd) acc = fmaf(m[r][k], w[k], acc);
+      cobj[(row0 + r) * d + c] = acc + bias;
+    }
+  }
 }
 
-// pstatic[b][j][:] = nan_to_num(e_j[b][:]) + pe[(j0 + j)][:]
-__global__ void prefix_pack_kernel(const float* __restrict__ e, float* __restrict__ pstatic, const float* __restrict__ pe,
-                                   int B, int d, int nrows, int j, int pe_row) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * d) return;
-  const int c = idx % d, b = idx / d;
-  pstatic[((long)b * nrows + j) * d + c] = nan_to_num(e[idx]) + pe[(long)pe_row * d + c];
-}
-
-// hand_side token: "rh" -> rh_embed, "lh" -> lh_embed
-__global__ void hand_side_kernel(const unsigned char* __restrict__ side, const float* __restrict__ rh,
-                                 const float* __restrict__ lh, float* __restrict__ out, int B, int d) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * d) return;
-  const int c = idx % d, b = idx / d;
-  out[idx] = side[b] ? lh[c] : rh[c];
-}
-
-// fp32 [R][C] -> operand planes [NP][R][ldo] (cols >= C zero-filled up to ldo)
 template <class Op>
 __global__ void pack_operand_kernel(const float* __restrict__ in, typename Op::elem_t* out, long R, int C, int ldo) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
