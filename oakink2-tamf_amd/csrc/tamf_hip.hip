@@ -292,9 +292,10 @@ static int upload_operand(tamf_ctx* ctx, int prec, const float* w, int N, int K,
 static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
-// 64 = f32: QKV on the 128 x 128 tiles, 512 = streaming attention kernel in the 16-bit modes too,
+// 16 = residual GEMMs of a few clips on the clip / 128 x 128 tiles too (no 32- / 64-row tiles), 64 = f32: QKV on the 128 x 128 tiles,
+// 512 = streaming attention kernel in the 16-bit modes too,
 // 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds.
-// (Rounds 2 - 5 also had 16 / 256 / 2048 / 4096: the LayerNorm-fused 64 x d tile, the GEMM + LayerNorm-kernel form and the row-block kernel
+// (Rounds 2 - 5 also had 16 (another meaning) / 256 / 2048 / 4096: the LayerNorm-fused 64 x d tile, the GEMM + LayerNorm-kernel form and the row-block kernel
 // of the residual GEMMs - gone with the deferred LayerNorm, which every mode uses now; 32 / 128: clip-tile variants of FFN1 / QKV that
 // lost their A/B.  The bits are accepted and ignored.)
 static int g_sel = 0;
@@ -508,6 +509,8 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmLaunch<Op, 64, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;  // (a few clips per call: launch_resid)
+  if ((e = GemmLaunch<Op, 32, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = prepare_clip<Op, 13, 7>()) != hipSuccess) return e;
@@ -1126,6 +1129,18 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
 // the same K order per element and the same statistics trees in all three, i.e. the same bits
 template <class Op>
 static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, int B, int Sp, hipStream_t st) {
+  // A few clips per call (one, in the reference's own launcher: launch/sample.py:202-229): whole-clip or row-part tiles would put
+  // 2 N / 128 workgroups on a clip - in f32 FFN2 of ONE clip ran 100 us on 8 CUs, MFMA-bound, 55 % of the step.  32 x 128 tiles (64 x 128
+  // while they still fit one workgroup per CU) put a CU on every 32 rows: the same W panel per workgroup, a third of the MFMA work, the
+  // same K order per element - i.e. the same bits.  f32: 1 463 -> 913 us per step at one clip, -9 % still at 24 clips.  The 16-bit modes
+  // take them for K <= 16 K tiles only (out-proj: 12.8 -> 10.7 us): their FFN2 is bound by the latency of its 64 K-tile intervals
+  // (0.55 us each in this double-buffered kernel, 37.6 us, against 33.7 us on the three-stage clip kernel), not by its MFMAs
+  // (profiles/r05/small_batch_resid_c25.txt).  (Selection bit 16: off, the A/B partner.)
+  if (!(g_sel & (1 | 16)) && ga.N % 128 == 0 && (Op::PREC == 0 || ga.K * Op::EB <= 16 * GEMM_BKB)) {
+    const int cus = g_wg_slots / 2, ntn = ga.N / 128;
+    if (((ga.M + 31) / 32) * ntn <= cus) return GemmLaunch<Op, 32, 128, EpiResid<Op>>::launch(ga, ep, st);
+    if (((ga.M + 63) / 64) * ntn <= cus) return GemmLaunch<Op, 64, 128, EpiResid<Op>>::launch(ga, ep, st);
+  }
   if (!(g_sel & 2)) {
     TAMF_CLIP_NSUB(Sp, {
       if (ClipLaunch<Op, 2, EpiResid<Op>, NSP, 2>::applies_parts(B, Sp, ga.N, ga.K))

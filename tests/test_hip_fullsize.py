@@ -426,6 +426,7 @@ SELECTIONS = {
     0x001: "no clip tiles at all (128 x 128 tiles everywhere)",
     0x002: "FFN2 / out-proj not on clip tiles",
     0x008: "FFN1 on the 128 x 128 tiles",
+    0x010: "residual GEMMs of a few clips without the 32- / 64-row tiles",
     0x040: "QKV on the 128 x 128 tiles (f32 default: clip tiles, Q|K and V transposed)",
     0x400: "clip tiles from 50 % utilisation",
 }
