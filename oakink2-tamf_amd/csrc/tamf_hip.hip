@@ -19,6 +19,7 @@
 #include "tamf_attn.h"
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
+#include "tamf_gemm_deep.h"
 #ifdef TAMF_BENCH  // the row-block LayerNorm GEMM of round 4 (measured, not faster: DESIGN.md): an A/B partner of the measurement builds only
 #endif
 #include "tamf_geom.h"
@@ -379,6 +380,48 @@ template <class Op, bool LN> struct EpiCanSplit<EpiBiasAct<Op, LN>> { static con
 template <class Op, bool LN> struct EpiCanSplit<EpiQKV<Op, LN>> { static constexpr bool value = true; };
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
 
+// Small tiles with a deep K pipeline (tamf_gemm_deep.h): launches of a few tiles, one workgroup each
+template <class Op, int BM, int BN, int NSTG, class Epi>
+struct GemmDeepLaunch {
+  static constexpr int SMEM = GemmSmemDeep<BM, BN, NSTG>::TOTAL;
+  static hipError_t prepare() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<Op, BM, BN, 2, 4, NSTG, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    return e;
+  }
+  static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
+    hipError_t e = prepare();
+    if (e != hipSuccess) return e;
+    if ((ga.K * Op::EB) % GEMM_BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
+    const int tiles = (ga.N / BN) * ((ga.M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_deep_kernel<Op, BM, BN, 2, 4, NSTG, Epi>), dim3(tiles), dim3(512), SMEM, st, ga, epi);
+    return hipGetLastError();
+  }
+};
+
+// A few clips per call (one, in the reference's own launcher: launch/sample.py:202-229): the tiles of the big batches would put a handful of
+// workgroups on the chip and each would walk its K tiles one L2 round trip at a time.  32 x 128 tiles (64 x 128 while they still fit one
+// workgroup per CU) with a four-stage K pipeline instead: a CU on every 32 rows, the same K order per element - the same bits.
+// Returns false when the launch is not that small (or selection bit 1 / 16 turns the small tiles off: the A/B partner).
+template <class Op, class Epi>
+static bool small_m_launch(const GemmArgs<Op>& ga, const Epi& ep, hipStream_t st, hipError_t* e) {
+  if ((g_sel & (1 | 16)) || ga.N % 128 != 0) return false;
+  const int cus = g_wg_slots / 2, ntn = ga.N / 128;
+  if (((ga.M + 31) / 32) * ntn <= cus) {
+    *e = GemmDeepLaunch<Op, 32, 128, 4, Epi>::launch(ga, ep, st);
+    return true;
+  }
+  if (((ga.M + 63) / 64) * ntn <= cus) {
+    *e = GemmDeepLaunch<Op, 64, 128, 4, Epi>::launch(ga, ep, st);
+    return true;
+  }
+  return false;
+}
+
 // Clip-aligned tiles (tamf_gemm_clip.h): one M tile = one clip of NSUB MFMA row tiles.  NSUB = 13 serves the bench shape (T = 196:
 // S = 201, Sp = 208), NSUB = 11 the length the reference's dataset emits (slice_max_len = 160, dataset/interaction_segment.py:291:
 // S = 165, Sp = 168 - the 11th row tile holds 8 rows, the rest of it is clamped on the load side and skipped on the store side);
@@ -509,8 +552,17 @@ static hipError_t prepare_all() {
   if ((e = GemmLaunch<Op, 128, 128, EpiBiasAct<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiQKV<Op, true>, true>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 128, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
-  if ((e = GemmLaunch<Op, 64, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;  // (a few clips per call: launch_resid)
-  if ((e = GemmLaunch<Op, 32, 128, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  // a few clips per call (small_m_launch): the encoder layers' GEMMs on 32- / 64-row tiles with the deep K pipeline
+  if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiQKV<Op, true>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiQKV<Op, true>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiBiasAct<Op, true>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiBiasAct<Op, true>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiHead<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiHead<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiBiasAct<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmLaunch<Op, 64, 128, EpiSeqRows<Op>>::prepare()) != hipSuccess) return e;
   if ((e = prepare_clip<Op, 13, 7>()) != hipSuccess) return e;
@@ -1129,17 +1181,11 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
 // the same K order per element and the same statistics trees in all three, i.e. the same bits
 template <class Op>
 static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, int B, int Sp, hipStream_t st) {
-  // A few clips per call (one, in the reference's own launcher: launch/sample.py:202-229): whole-clip or row-part tiles would put
-  // 2 N / 128 workgroups on a clip - in f32 FFN2 of ONE clip ran 100 us on 8 CUs, MFMA-bound, 55 % of the step.  32 x 128 tiles (64 x 128
-  // while they still fit one workgroup per CU) put a CU on every 32 rows: the same W panel per workgroup, a third of the MFMA work, the
-  // same K order per element - i.e. the same bits.  f32: 1 463 -> 913 us per step at one clip, -9 % still at 24 clips.  The 16-bit modes
-  // take them for K <= 16 K tiles only (out-proj: 12.8 -> 10.7 us): their FFN2 is bound by the latency of its 64 K-tile intervals
-  // (0.55 us each in this double-buffered kernel, 37.6 us, against 33.7 us on the three-stage clip kernel), not by its MFMAs
-  // (profiles/r05/small_batch_resid_c25.txt).  (Selection bit 16: off, the A/B partner.)
-  if (!(g_sel & (1 | 16)) && ga.N % 128 == 0 && (Op::PREC == 0 || ga.K * Op::EB <= 16 * GEMM_BKB)) {
-    const int cus = g_wg_slots / 2, ntn = ga.N / 128;
-    if (((ga.M + 31) / 32) * ntn <= cus) return GemmLaunch<Op, 32, 128, EpiResid<Op>>::launch(ga, ep, st);
-    if (((ga.M + 63) / 64) * ntn <= cus) return GemmLaunch<Op, 64, 128, EpiResid<Op>>::launch(ga, ep, st);
+  // a few clips per call: whole-clip or row-part tiles would put 2 N / 128 workgroups on a clip - FFN2 of ONE clip ran 34 us (f32: 100 us)
+  // on 8 CUs, 40 - 55 % of the step (profiles/r05/small_batch_resid_c25.txt, ..._c27.txt)
+  {
+    hipError_t e = hipSuccess;
+    if (small_m_launch<Op>(ga, ep, st, &e)) return e;
   }
   if (!(g_sel & 2)) {
     TAMF_CLIP_NSUB(Sp, {
@@ -1180,7 +1226,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
     // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
     EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_st, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off, {ctx->Wm2.inv_scale, ctx->status}};
-    HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+    hipError_t es = hipSuccess;
+    if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
+    else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
@@ -1218,7 +1266,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
           }
           if (!on_clip) {
             EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, ln_in};
-            HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+            hipError_t es = hipSuccess;
+            if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
+            else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
             mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
           }
         }
@@ -1245,7 +1295,11 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
               }
             })
           }
-          if (!on_clip) HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+          if (!on_clip) {
+            hipError_t es = hipSuccess;
+            if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
+            else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+          }
           mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
         }
         {
@@ -1262,7 +1316,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)ctx->Wf.p, d, M, ctx->XN, d, 0};
     EpiHead<Op> head = head_in;
     head.t_off = t_off;
-    HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head, st)));
+    hipError_t es = hipSuccess;
+    if (small_m_launch<Op>(ga, head, st, &es)) HIPCHK(ctx, es);  // (a few clips per call)
+    else HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head, st)));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
   ctx->step_kernels = nk;
@@ -1615,8 +1671,11 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   if (resid) {
     // the residual GEMM of an encoder sublayer with the LayerNorm of its input deferred (EpiResid): c holds u on entry, u_next on return
     EpiResid<Op> ep{bias, gamma, c, Op::PREC == 0 ? nullptr : yo, N, stats_out, ACT_NONE, {}, LnStats{stats_in, N / 32, 1.0f / (float)N, 1e-5f}};
+    // (the selection of the step: launch_resid for clip-aligned M - small tiles with the deep K pipeline when there are few of them - and
+    // for every other M the small tiles where they fit, so that ragged tile edges of that kernel are tested too, else 128 x 128)
     const int sp = M % 208 == 0 ? 208 : (M % 168 == 0 ? 168 : 0);
-    e = sp ? launch_resid<Op>(ga, ep, M / sp, sp, st) : gemm128<Op>(ga, ep, st);
+    if (sp) e = launch_resid<Op>(ga, ep, M / sp, sp, st);
+    else if (!small_m_launch<Op>(ga, ep, st, &e)) e = gemm128<Op>(ga, ep, st);
   } else {
     EpiStoreF32 ep{bias, c, N, act};
     // M = n * 208 rows (T = 196) or n * 168 rows (T = 160): the clip-aligned tiles the encoder layers use (same selection as

@@ -102,6 +102,43 @@ def check(path, log=None):
     return n
 
 
+def check_deep(path, log=None):
+    """The small tiles with the deep K pipeline (csrc/tamf_gemm_deep.h): a wave waits with s_waitcnt vmcnt(PW * (NSTG - 2)) for the K tile
+    it reads next, PW = the LDS-DMA pieces it requests per K tile - correct only while hipcc emits exactly one global_load_lds per source-level
+    request (NSTG - 1 batches in the prologue, one in the K loop) and keeps the two counted waits.  Returns the number of instantiations."""
+    lines = open(path).read().split("\n")
+    n, bad, i = 0, [], 0
+    while i < len(lines):
+        m = re.match(r"^(_Z16gemm_deep_kernelI\d+(Op[A-Z0-9]+)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\w+):", lines[i])
+        if m:
+            j = i
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+                j += 1
+            if j >= len(lines):
+                raise IsaMismatch("no .Lfunc_end label behind " + m.group(1))
+            body = lines[i:j]
+            bm, bn, wgm, wgn, nstg = (int(m.group(k)) for k in range(3, 8))
+            nwv, a_pieces, w_pieces = wgm * wgn, bm // 8, bn // 8
+            a_pw, w_pw, a_rem = -(-a_pieces // nwv), w_pieces // nwv, a_pieces % nwv
+            want_dma = nstg * (a_pw + w_pw)
+            waits = {int(x.group(1)) for l in body for x in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if x}
+            need = {(a_pw + w_pw) * (nstg - 2)} | ({(a_pw - 1 + w_pw) * (nstg - 2)} if a_rem else set())
+            dma = sum(1 for l in body if l.strip().startswith("global_load_lds"))
+            spill = any(l.strip().startswith("scratch_") for l in body)
+            ok = dma == want_dma and need <= waits and not spill
+            line = f"{'ok ' if ok else 'BAD'} {m.group(2):8s} {bm}x{bn} NSTG={nstg}: global_load_lds {dma} (expected {want_dma}), counted waits needed {sorted(need)}, seen {sorted(waits)}"
+            if log:
+                log(line)
+            if not ok:
+                bad.append(line)
+            n += 1
+            i = j
+        i += 1
+    if bad:
+        raise IsaMismatch(f"{len(bad)} of {n} gemm_deep_kernel instantiations do not match the request counts of tamf_gemm_deep.h:\n" + "\n".join(bad))
+    return n
+
+
 SCRATCH_LIMIT = 32  # bytes per lane
 
 

@@ -103,8 +103,9 @@ def _build_locked(hipcc: str, verbose: bool) -> str:
             if asm is None:
                 raise _isa_check.IsaMismatch("hipcc left no device assembly to check")
             n = _isa_check.check(asm)
+            nd = _isa_check.check_deep(asm)
             if verbose:
-                print(f"ISA check: all {n} clip_gemm_kernel instantiations match the counted waits")
+                print(f"ISA check: all {n} clip_gemm_kernel and {nd} gemm_deep_kernel instantiations match the counted waits")
             try:  # register spilling in a hot kernel is a performance bug, not a correctness one: reported, never fatal
                 _isa_check.check_scratch(asm)
             except _isa_check.IsaMismatch as e:

@@ -17,4 +17,5 @@ def test_clip_gemm_store_count_matches_the_counted_waits():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_clip_stores.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "clip_gemm_kernel instantiations match" in r.stdout
+    assert "gemm_deep_kernel instantiations match" in r.stdout  # (csrc/tamf_gemm_deep.h: one LDS-DMA instruction per counted request)
     assert "no register spilling beyond" in r.stdout  # (attention + clip-GEMM kernels: private segment <= 32 bytes per lane)

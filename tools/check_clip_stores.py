@@ -40,6 +40,11 @@ def main():
         raise SystemExit(str(e))
     print(f"all {n} clip_gemm_kernel instantiations match")
     try:
+        nd = _isa_check.check_deep(path, log=print)
+    except _isa_check.IsaMismatch as e:
+        raise SystemExit(str(e))
+    print(f"all {nd} gemm_deep_kernel instantiations match")
+    try:
         k = _isa_check.check_scratch(path, log=print)
     except _isa_check.IsaMismatch as e:
         raise SystemExit(str(e))
