@@ -555,6 +555,9 @@ static hipError_t prepare_all() {
   // a few clips per call (small_m_launch): the encoder layers' GEMMs on 32- / 64-row tiles with the deep K pipeline
   if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  if constexpr (Op::PREC != 0) {  // 20 - 39 clips per call, 16-bit modes (launch_resid)
+    if ((e = GemmDeepLaunch<Op, 64, 128, 3, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  }
   if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiQKV<Op, true>>::prepare()) != hipSuccess) return e;
   if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiQKV<Op, true>>::prepare()) != hipSuccess) return e;
   if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiBiasAct<Op, true>>::prepare()) != hipSuccess) return e;
@@ -1186,6 +1189,15 @@ static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, i
   {
     hipError_t e = hipSuccess;
     if (small_m_launch<Op>(ga, ep, st, &e)) return e;
+  }
+  // Between "a few clips" and the whole-clip tiles (20 - 39 clips): 64 x 128 tiles with THREE stages - 72 KB, two workgroups per CU - while
+  // they fit the workgroup slots.  bf16, whose K tiles are the shortest: 0.815 against 0.850 ms per step at 32 clips on the row-part tiles
+  // (-4 %; profiles/r05/mid_batch_resid_c33.txt, variants alternating); the split modes gain up to ~ 1.25 tiles per CU only (24 clips:
+  // -3 %; 32 clips: 1.510 against 1.510), f32 loses (MFMA-bound: the row parts multiply with fewer staged bytes per flop).  At 64 clips
+  // the whole-clip tiles win by a wide margin (b64_resid_deep_c34.txt).  Same K order per element: the same bits.
+  if (!(g_sel & (1 | 16)) && Op::PREC != 0 && ga.N % 128 == 0) {
+    const int t64 = ((ga.M + 63) / 64) * (ga.N / 128);
+    if (Op::SPLIT ? t64 * 4 <= g_wg_slots / 2 * 5 : t64 <= g_wg_slots) return GemmDeepLaunch<Op, 64, 128, 3, EpiResid<Op>>::launch(ga, ep, st);
   }
   if (!(g_sel & 2)) {
     TAMF_CLIP_NSUB(Sp, {
