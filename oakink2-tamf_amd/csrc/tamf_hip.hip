@@ -381,7 +381,7 @@ template <class Op, bool LN> struct EpiCanSplit<EpiQKV<Op, LN>> { static constex
 template <> struct EpiCanSplit<EpiStoreF32> { static constexpr bool value = true; };
 
 // Small tiles with a deep K pipeline (tamf_gemm_deep.h): launches of a few tiles, one workgroup each
-template <class Op, int BM, int BN, int NSTG, class Epi>
+template <class Op, int BM, int BN, int NSTG, class Epi, int WGM = 2, int WGN = 4>
 struct GemmDeepLaunch {
   static constexpr int SMEM = GemmSmemDeep<BM, BN, NSTG>::TOTAL;
   static hipError_t prepare() {
@@ -389,7 +389,7 @@ struct GemmDeepLaunch {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<Op, BM, BN, 2, 4, NSTG, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<Op, BM, BN, WGM, WGN, NSTG, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
   }
@@ -398,7 +398,7 @@ struct GemmDeepLaunch {
     if (e != hipSuccess) return e;
     if ((ga.K * Op::EB) % GEMM_BKB != 0 || ga.N % BN != 0 || ga.M <= 0) return hipErrorInvalidValue;
     const int tiles = (ga.N / BN) * ((ga.M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_deep_kernel<Op, BM, BN, 2, 4, NSTG, Epi>), dim3(tiles), dim3(512), SMEM, st, ga, epi);
+    hipLaunchKernelGGL((gemm_deep_kernel<Op, BM, BN, WGM, WGN, NSTG, Epi>), dim3(tiles), dim3(WGM * WGN * 64), SMEM, st, ga, epi);
     return hipGetLastError();
   }
 };
@@ -555,6 +555,7 @@ static hipError_t prepare_all() {
   // a few clips per call (small_m_launch): the encoder layers' GEMMs on 32- / 64-row tiles with the deep K pipeline
   if ((e = GemmDeepLaunch<Op, 64, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
   if ((e = GemmDeepLaunch<Op, 32, 128, 4, EpiResid<Op>>::prepare()) != hipSuccess) return e;
+  if ((e = GemmDeepLaunch<Op, 32, 64, 6, EpiResid<Op>, 2, 2>::prepare()) != hipSuccess) return e;
   if constexpr (Op::PREC != 0) {  // 20 - 39 clips per call, 16-bit modes (launch_resid)
     if ((e = GemmDeepLaunch<Op, 64, 128, 3, EpiResid<Op>>::prepare()) != hipSuccess) return e;
   }
@@ -1186,6 +1187,11 @@ template <class Op>
 static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, int B, int Sp, hipStream_t st) {
   // a few clips per call: whole-clip or row-part tiles would put 2 N / 128 workgroups on a clip - FFN2 of ONE clip ran 34 us (f32: 100 us)
   // on 8 CUs, 40 - 55 % of the step (profiles/r05/small_batch_resid_c25.txt, ..._c27.txt)
+  // one to ~ 6 clips: 32 x 64 tiles (4 waves, six stages) while they fit one workgroup per CU - half the L2 -> LDS fill per workgroup and K
+  // interval of the 32 x 128 tile, which is what a one-clip FFN2 was left bound by: 19.1 -> 14.2 us (f16x3), 10.3 -> 7.3 (bf16), 46.9 -> 25.5
+  // (f32); the step of one clip 434 -> 385 / 256 -> 226 / 900 -> 686 us (profiles/r05/small_batch_32x64_c37.txt; same bits)
+  if (!(g_sel & (1 | 16)) && ga.N % 64 == 0 && ((ga.M + 31) / 32) * (ga.N / 64) <= g_wg_slots / 2)
+    return GemmDeepLaunch<Op, 32, 64, 6, EpiResid<Op>, 2, 2>::launch(ga, ep, st);
   {
     hipError_t e = hipSuccess;
     if (small_m_launch<Op>(ga, ep, st, &e)) return e;
