@@ -450,6 +450,30 @@ def test_kernel_selections_give_the_same_bits(full, prec):
         ctx.close()
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_small_and_mid_batch_tiles_give_the_same_bits(full, full160, prec):
+    """Calls of a few clips run their GEMMs on gemm_deep_kernel (csrc/tamf_gemm_deep.h: 32 x 64 / 32 x 128 / 64 x 128 tiles with a 3- to
+    6-stage K pipeline; one clip per call is the reference launcher's own pattern, launch/sample.py:202-229), 20 - 39 clips of the 16-bit
+    modes their residual GEMMs: same bits as the tiles of the big batches (selection bit 16), and within the tolerance of the oracle."""
+    from oakink2_tamf_amd.hip_backend import lib
+
+    for fx, T, Bs in ((full, T_FULL, (1, 2, 5, 9, 17, 24, 33)), (full160, T_DS, (1, 3, 6, 12, 30))):
+        for B in Bs:
+            cond, x, t = _sub(fx["cond"], slice(0, B)), fx["x"][:B], fx["t"][:B]
+            ctx = _make_ctx(fx["arch"], fx["sd"], B, T, prec)
+            _set_cond(ctx, cond)
+            try:
+                ref = ctx.denoise(x, t).cpu()
+                lib().tamf_set_gemm_tuning((0x010 << 20) | 0xFFFFF)
+                got = ctx.denoise(x, t).cpu()
+            finally:
+                lib().tamf_set_gemm_tuning(-1)
+                ctx.close()
+            assert torch.equal(got, ref), (prec, B, T, float((got - ref).abs().max()))
+            err = float((ref - fx["ref"][:B]).abs().max())
+            assert err < FWD_TOL[prec], (prec, B, T, err)
+
+
 # ---- T = 160: the only clip length the reference's dataset emits (dataset/interaction_segment.py:291, slice_max_len = 160) ------------
 # S = 165, padded to Sp = 168 rows = 10.5 MFMA row tiles: clip tiles of 11 row tiles (6 + 5 as row parts at 32 clips per GPU), the
 # resident-K attention with 12 key tiles, 64-row LayerNorm blocks that straddle clips, V^T rows of 192 keys.
