@@ -304,6 +304,75 @@ def cpu_baseline(arch_name, sd, B, T, n_ddpm, timed=5):
     }
 
 
+def torch_rocm_baseline(arch_name, sd, cond, B, T, n_ddpm, dev, check_in=None, timed=10):
+    """Same-box LIBRARY yardstick (outside every timed region of the product path, never in it): what the reference's own code path
+    - launch/sample.py:213-229 on PyTorch-ROCm, i.e. hipBLASLt / rocBLAS GEMMs + torch's attention - delivers on THIS board under the
+    same power cap, on the same weights, batch and clip length as the headline.  Two forms of the denoiser x two arithmetic types:
+      "oracle_algebra"       oracle.denoiser_forward (plain tensor algebra: matmul / softmax / matmul) with its tensors on the device;
+      "nn_transformer_encoder"  the same forward with torch's own nn.TransformerEncoder - the module the reference instantiates
+                             (model/interaction_segment_mdm.py:63-70: seq-first, gelu, eval) - as the encoder: F.multi_head_attention_forward
+                             -> scaled_dot_product_attention;
+      fp32, and bf16 under torch.autocast.
+    2 warm-up + `timed` denoiser + DDPM steps (conditioning recomputed every step, as the reference does, CLIP excluded), HIP-synchronised,
+    extrapolated to the n_ddpm-step loop exactly like cpu_baseline.  A reported baseline, not the product: nothing here is shipped."""
+    import torch
+
+    from oracle import mdm_oracle as O
+
+    arch = {"arch_mdm": O.ARCH_MDM, "arch_mdm_l": O.ARCH_MDM_L}[arch_name]
+    sd_dev = {k: v.to(dev) for k, v in sd.items()}
+    cond_dev = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in cond.items()}
+    tab = O.make_tables(n_ddpm, "cosine")
+    d = arch.latent_dim
+    layer = torch.nn.TransformerEncoderLayer(d_model=d, nhead=arch.num_heads, dim_feedforward=arch.ff_size, dropout=0.1, activation="gelu")
+    enc = torch.nn.TransformerEncoder(layer, num_layers=arch.num_layers)
+    enc.load_state_dict({k[len("seqTransEncoder."):]: v for k, v in sd.items() if k.startswith("seqTransEncoder.")})
+    enc = enc.to(dev).eval()
+
+    def nn_encoder(seq):  # batch-first in / out; the module runs seq-first as in the reference
+        return enc(seq.transpose(0, 1)).transpose(0, 1)
+
+    out = {"what": "the oracle / torch's nn.TransformerEncoder on the device through PyTorch-ROCm's libraries: same box, same weights, same (B, T); "
+                   "a reported yardstick outside the product path", "torch": torch.__version__, "hip": torch.version.hip, "variants": {}}
+    g = torch.Generator().manual_seed(0)
+    x_init = torch.randn(B, 99, 1, T, generator=g).to(dev)
+    noise = torch.randn(B, 99, 1, T, generator=g).to(dev)
+    for form, encoder in (("oracle_algebra", None), ("nn_transformer_encoder", nn_encoder)):
+        for dt_name in ("f32", "bf16_autocast"):
+            try:
+                x = x_init.clone()
+                times = []
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dt_name != "f32")):
+                    for it in range(2 + timed):
+                        i = n_ddpm - 1 - it
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        x0 = O.denoiser_forward(sd_dev, arch, x, torch.full((B,), i, dtype=torch.long, device=dev), cond_dev, encoder=encoder)
+                        x = O.ddpm_step(tab, x, x0.float(), i, noise)
+                        torch.cuda.synchronize(dev)
+                        times.append(time.perf_counter() - t0)
+                    err = None
+                    if check_in is not None:
+                        xc, tc, ref, nc = check_in
+                        sub = {k: (v[:nc] if hasattr(v, "to") else list(v[:nc])) for k, v in cond_dev.items()}
+                        got = O.denoiser_forward(sd_dev, arch, xc[:nc].to(dev), tc[:nc].to(dev), sub, encoder=encoder)
+                        err = float((got.float().cpu() - ref).abs().max())
+                step_s = sum(times[2:]) / timed
+                tf = flops_per_clip_step(ARCHS[arch_name], T) * B / step_s / 1e12
+                out["variants"][f"{form}/{dt_name}"] = {
+                    "value": B * T / (step_s * n_ddpm), "unit": "frames/s", "ms_per_ddpm_step": step_s * 1e3, "whole_path_tflops": tf,
+                    "max_abs_err_vs_cpu_oracle": err, "sample": f"{timed} timed denoiser+DDPM steps after 2 warm-up, extrapolated to {n_ddpm}"}
+            except Exception as e:  # noqa: BLE001  (a yardstick that cannot run must not take the bench line with it)
+                out["variants"][f"{form}/{dt_name}"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    ok = {k: v for k, v in out["variants"].items() if "value" in v}
+    if ok:
+        for cls, pick in (("f32", [k for k in ok if k.endswith("/f32")]), ("bf16", [k for k in ok if k.endswith("/bf16_autocast")])):
+            if pick:
+                best = max(pick, key=lambda k: ok[k]["value"])
+                out[f"best_{cls}"] = {"variant": best, "value": ok[best]["value"], "ms_per_ddpm_step": ok[best]["ms_per_ddpm_step"]}
+    return out
+
+
 def oracle_reference(arch_name, sd, cond, x, t, n_check):
     """oracle.denoiser_forward on the first n_check clips of the bench batch (outside every timed region)."""
     import torch
@@ -407,9 +476,10 @@ def parse_args(argv):
     ap.add_argument("--frames", type=int, default=196)
     ap.add_argument("--ddpm-steps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the same-box PyTorch-ROCm library yardstick (torch_rocm_baseline)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not start the power / clock sampler child")
-    ap.add_argument("--check-clips", type=int, default=2, help="clips of the in-run oracle check (0 = off)")
+    ap.add_argument("--check-clips", type=int, default=8, help="clips of the in-run oracle check (0 = off)")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile of one step here (json)")
     ap.add_argument("--also", default=None,
                     help="comma list of extra dtypes measured with 1 loop each on 1 GPU (other_dtypes); default: all other modes; '' = none")
@@ -732,7 +802,8 @@ def main(argv=None, sampler_factory=None):
         nc = min(args.check_clips, B)
         g = torch.Generator().manual_seed(4242)
         xc = torch.randn(B, 99, 1, T, generator=g)
-        tc = torch.full((B,), N // 2, dtype=torch.long)
+        # the checked clips sit at different points of the schedule (t is per clip in the denoiser's contract, respace.py:114-119)
+        tc = torch.tensor([(N // 2, 0, N - 1, N // 4, 3 * N // 4, 1, N - 2, N // 3)[b % 8] for b in range(B)], dtype=torch.long)
         ref = oracle_reference(args.arch, sd, cond, xc, tc, nc)
         check_in = (xc, tc, ref, nc)
         sampler.set_cond(cond_dev)
@@ -927,7 +998,7 @@ def main(argv=None, sampler_factory=None):
                                               "sets the step time; frac stays achieved / nominal MFMA peak" % (power["sclk_mhz"], power["watts"]))
         if check:
             line["check"] = {"max_abs_err_vs_oracle": check, "tolerance": {d: CHECK_TOL[d] for d in check},
-                             "what": f"one denoiser evaluation (t={N // 2}) of the first "
+                             "what": f"one denoiser evaluation (t = N/2, 0, N-1, N/4, 3N/4, 1, N-2, N/3 by clip) of the first "
                              f"{min(args.check_clips, B)} clips of the bench batch vs oracle.denoiser_forward (fp32 torch-CPU restatement of the reference), outputs O(1)"}
         ok = checks_ok(finite_by, range_flags, check)
         if range_flags:
@@ -936,6 +1007,16 @@ def main(argv=None, sampler_factory=None):
         line["check_ok"] = ok  # every reported dtype: finite samples, oracle check inside its tolerance, no range flag
         if other:
             line["other_dtypes"] = other
+        if not args.no_torch_baseline and world == 1 and not stub:
+            # same-box library yardstick: the reference's own op sequence through PyTorch-ROCm (hipBLASLt / SDPA), after every timed region
+            tb = torch_rocm_baseline(args.arch, sd, cond, B, T, N, dev, check_in)
+            line["torch_rocm_baseline"] = tb
+            mine = {"f32": (line.get("fp32") or {}).get("value"), "bf16": (other.get("bf16") or {}).get("value") if args.dtype != "bf16" else value,
+                    args.dtype: value}
+            tb["product_over_library"] = {
+                "headline_%s_over_library_f32" % args.dtype: value / tb["best_f32"]["value"] if "best_f32" in tb else None,
+                "f32_over_library_f32": mine["f32"] / tb["best_f32"]["value"] if mine.get("f32") and "best_f32" in tb else None,
+                "bf16_over_library_bf16": mine["bf16"] / tb["best_bf16"]["value"] if mine.get("bf16") and "best_bf16" in tb else None}
         if not args.no_cpu_baseline and world == 1 and not stub:  # at N = 1 only (one host measurement, not one per scaling point)
             line["cpu_baseline"] = cpu_baseline(args.arch, sd, B, T, N)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -350,10 +350,13 @@ def denoiser_forward(
     t: torch.Tensor,
     cond: Dict[str, object],
     dtype: torch.dtype = torch.float32,
+    encoder: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
 ) -> torch.Tensor:
     """InterationSegmentMDM.forward (model/interaction_segment_mdm.py:134-174), CLIP output supplied as
     cond["text_embedding"] (the value encode_text(...).float() would return, :132).
-    x: (B, 99, 1, T); t: (B,) int; returns (B, 99, 1, T)."""
+    x: (B, 99, 1, T); t: (B,) int; returns (B, 99, 1, T).
+    `encoder` (batch-first (B, S, d) -> (B, S, d)) replaces encoder_stack: bench.py's same-box library yardstick passes torch's own
+    nn.TransformerEncoder there (the module the reference instantiates, :63-70); every parity use leaves it None."""
     assert arch.kind == "G"
     B, F, _, T = x.shape
     dt = dtype
@@ -376,7 +379,7 @@ def denoiser_forward(
 
     seq = torch.cat([prefix, h], dim=1)  # (B, S, d)
     seq = seq + pe[: seq.shape[1]].unsqueeze(0)  # (:169-170, :195-198; dropout inactive)
-    seq = encoder_stack(sd, arch, seq)[:, arch.prefix_len :, :]
+    seq = (encoder(seq) if encoder is not None else encoder_stack(sd, arch, seq))[:, arch.prefix_len :, :]
     out = _lin(sd, "output_process.poseFinal", seq)  # (B, T, 99)
     out = out.transpose(1, 2).unsqueeze(2)  # (B, 99, 1, T) (:313-318)
     return torch.nan_to_num(out)
