@@ -96,8 +96,10 @@ int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t max_frames
 /* Re-dimension the context for up to max_batch clips of up to max_frames frames: the workspaces (sampler state, token rows, operand
  * planes, scratch) are freed and allocated anew; weights, tables and the schedule stay, so no checkpoint is uploaded or repacked again
  * (a launcher whose clip source changes shape, launch/sample.py:204-215 / launch/sample_refine.py:224-236, pays milliseconds).
- * Synchronises the device, drops the captured hipGraph and the conditioning (tamf_set_cond must be called again) and clears the
- * context's status word.  On failure the context can only be destroyed. */
+ * Synchronises the device, drops the captured hipGraph and the conditioning (tamf_set_cond must be called again).  The context's
+ * sticky status word is carried over (a range flag not yet read survives).  Transactional: the new workspaces are allocated beside
+ * the old ones, which are freed only when every allocation has succeeded; on failure (TAMF_ERR_NOMEM: the larger batch does not fit)
+ * the context keeps its old dimensions, workspaces and conditioning and stays usable. */
 int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_frames);
 void tamf_ctx_destroy(tamf_ctx* ctx);
 const char* tamf_last_error(const tamf_ctx* ctx);
@@ -262,6 +264,10 @@ int tamf_test_check_guards(tamf_ctx* ctx, int32_t* n_checked);
 /* The checker's own test: zero nbytes at `offset` from the start of guarded allocation #alloc_index (negative / beyond-the-end offsets
  * reach into its margins). */
 int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset, int32_t nbytes);
+/* Failure injection for the allocation paths: the (n + 1)-th device allocation this process makes from now on fails with
+ * TAMF_ERR_NOMEM (n = 0: the next one; -1 disarms).  tests/test_hip_guardbands.py uses it to prove that a tamf_ctx_resize which
+ * runs out of memory leaves the context working at its old size. */
+int tamf_test_fail_alloc_after(int32_t n);
 /* Philox normal draws exactly as the sampling loop generates them: out (B, n_feat, 1, T). */
 int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
                      float* out_dev, void* stream);

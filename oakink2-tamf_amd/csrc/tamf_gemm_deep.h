@@ -121,7 +121,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_deep_kernel(const GemmArgs
   }
   float2* const rstat = (float2*)(smem + SM::STATS_OFF);
   if constexpr (Epi::ROWSTATS) ln_stage<NT, Epi::STAGE_AFF, (BM + NT / 4 - 1) / (NT / 4)>(epi.ln, epi.ctl.wscale, m0, BM, M, rstat, tid);
-  __syncthreads();  // (vmcnt(0): the whole prologue has landed)
+  // the whole prologue has landed: an EXPLICIT vmcnt(0) in front of the barrier (a plain __syncthreads() left it to hipcc's
+  // fence lowering, and with no LayerNorm staged - layer 0's out-proj - nothing else forces a wait in front of the first LDS reads;
+  // _isa_check.check_deep asserts the wait on the build's own assembly)
+  clip_wait_vm<0>();
+  clip_barrier_lds();
 
   int sc = 0, sn = LA % NSTG;
   for (int kt = 0; kt < KT; ++kt) {

@@ -170,9 +170,12 @@ static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+static std::atomic<int> g_fail_alloc_in{-1};  // test hook (tamf_test_fail_alloc_after): the n-th device allocation from now fails
 static int dev_alloc(tamf_ctx* ctx, void** p, size_t bytes, bool zero = false) {
   if (bytes == 0) bytes = 16;
   const size_t guard = g_guard_bytes.load();
+  if (g_fail_alloc_in.load() >= 0 && g_fail_alloc_in.fetch_sub(1) == 0)
+    return fail(ctx, TAMF_ERR_NOMEM, "hipMalloc failed: injected by tamf_test_fail_alloc_after");
   hipError_t e = hipMalloc(p, bytes + 2 * guard);
   if (e != hipSuccess) return fail(ctx, TAMF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
   (ctx->alloc_ws ? ctx->ws_allocs : ctx->allocs).push_back(*p);
@@ -302,8 +305,16 @@ static int g_krot = -1;
 static int g_sel = 0;
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
-// resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch
-static int g_wg_slots = 512;
+// resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch.  Per DEVICE (one
+// process-wide word followed the device of the context created last): written by tamf_ctx_create under the launch lock, read for the
+// calling thread's current device - every entry point that enqueues kernels has made its context's device current.
+static int g_wg_slots_dev[64];
+static inline int wg_slots() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int v = g_wg_slots_dev[dev & 63];
+  return v > 0 ? v : 512;
+}
 
 template <class Op, int BM, int BN, class Epi, bool CAN_SPLIT = false>
 struct GemmLaunch {
@@ -351,7 +362,7 @@ struct GemmLaunch {
       // (measured: slices sharing a CU take as long as the whole tiles did, FFN1 93.5 -> 89 us with 2 x 128 slices)
       // (a launch of less than one round is sliced as long as the slices fit the workgroup slots: two slices sharing a CU
       // overlap each other's latencies, one whole tile alone on a CU does not)
-      const int n_full = (tiles / g_wg_slots) * g_wg_slots, rem = tiles - n_full, cus = n_full ? g_wg_slots / 2 : g_wg_slots;
+      const int n_full = (tiles / wg_slots()) * wg_slots(), rem = tiles - n_full, cus = n_full ? wg_slots() / 2 : wg_slots();
       if (rem > 0) {
         split = (rem * 4 <= cus) ? 4 : (rem * 2 <= cus) ? 2 : 1;
         if (split > 1) gb.n_full = n_full;
@@ -361,9 +372,9 @@ struct GemmLaunch {
     int nblk = gb.n_full + (tiles - gb.n_full) * split;
     // more than one round, a partial last round and no slices: a persistent one-round grid balances the CUs (the hardware
     // hands a freed slot to the next workgroup greedily; QKV's 1248 tiles ended up as 4..6 per CU instead of 4..5)
-    if (split == 1 && BM == 128 && tiles > g_wg_slots && tiles % g_wg_slots != 0) {
+    if (split == 1 && BM == 128 && tiles > wg_slots() && tiles % wg_slots() != 0) {
       gb.n_tiles = tiles;
-      nblk = g_wg_slots;
+      nblk = wg_slots();
     }
     const dim3 grid(nblk), block(WGM * WGN * 64);
     if constexpr (CAN_SPLIT) {
@@ -410,7 +421,7 @@ struct GemmDeepLaunch {
 template <class Op, class Epi>
 static bool small_m_launch(const GemmArgs<Op>& ga, const Epi& ep, hipStream_t st, hipError_t* e) {
   if ((g_sel & (1 | 16)) || ga.N % 128 != 0) return false;
-  const int cus = g_wg_slots / 2, ntn = ga.N / 128;
+  const int cus = wg_slots() / 2, ntn = ga.N / 128;
   if (((ga.M + 31) / 32) * ntn <= cus) {
     *e = GemmDeepLaunch<Op, 32, 128, 4, Epi>::launch(ga, ep, st);
     return true;
@@ -475,7 +486,7 @@ struct ClipLaunch {
   static bool applies(int n_clips, int Sp, int N, int K, int min_util = 74) {
     static_assert(PARTS == 1, "whole-clip tiles");
     if (!shape_ok(Sp, N, K)) return false;
-    const int cus = g_wg_slots / 2, tiles = n_clips * (N / C::BN), rounds = (tiles + cus - 1) / cus;
+    const int cus = wg_slots() / 2, tiles = n_clips * (N / C::BN), rounds = (tiles + cus - 1) / cus;
     return tiles * 100 >= rounds * cus * ((g_sel & 1024) ? 50 : min_util);  // >= 74 % of the workgroup slots of its rounds are used (A/B: 50 %)
   }
   static hipError_t launch(const Op*, const typename Op::elem_t* A, int lda, const typename Op::elem_t* W, int ldw, int n_clips,
@@ -487,7 +498,7 @@ struct ClipLaunch {
     constexpr int split_rows = PARTS == 1 ? 0 : NSUB * 16;
     ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, PARTS * n_clips * (N / C::BN), split_rows,
                         g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
-    const int cus = g_wg_slots / 2;
+    const int cus = wg_slots() / 2;
     hipLaunchKernelGGL((clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
   }
@@ -495,7 +506,7 @@ struct ClipLaunch {
   static bool applies_parts(int n_clips, int Sp, int N, int K) {
     static_assert(PARTS == 2, "row-part tiles");
     if (!shape_ok(Sp, N, K) || Sp <= C::MT) return false;
-    const int cus = g_wg_slots / 2, whole = n_clips * (N / C::BN);
+    const int cus = wg_slots() / 2, whole = n_clips * (N / C::BN);
     return whole * 2 <= cus;
   }
 };
@@ -518,7 +529,7 @@ template <class Op, class Epi>
 static hipError_t gemm128(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
   if constexpr (EpiHasSmallTile<Epi>::value) {
     const int t128 = ((ga.M + 127) / 128) * (ga.N / 128);
-    if (!(g_sel & 1) && ga.N % 128 == 0 && t128 * 2 <= g_wg_slots && ga.K * Op::EB <= 2048)
+    if (!(g_sel & 1) && ga.N % 128 == 0 && t128 * 2 <= wg_slots() && ga.K * Op::EB <= 2048)
       return GemmLaunch<Op, 64, 128, Epi>::launch(ga, epi, st);
   }
   return GemmLaunch<Op, 128, 128, Epi, EpiCanSplit<Epi>::value>::launch(ga, epi, st);
@@ -598,7 +609,7 @@ static hipError_t launch_attn(const AttnArgs<Op>& aa, int B, int hd, hipStream_t
   int chunks = (nqt + nw_max - 1) / nw_max;
   // fewer (clip, head) pairs than CUs (B = 32: 128): split the queries of a pair over workgroups until the chip is filled;
   // K/V are then streamed once per workgroup, which costs less than idle CUs (a query's result does not depend on the split)
-  while (chunks * B * aa.H < g_wg_slots / 2 && chunks * 2 <= nqt) chunks *= 2;
+  while (chunks * B * aa.H < wg_slots() / 2 && chunks * 2 <= nqt) chunks *= 2;
   if ((g_sel & 4) && chunks * 2 <= nqt) chunks *= 2;  // A/B: one more split (two workgroups per CU at B = 64)
   const int nw = (nqt + chunks - 1) / chunks;
   dim3 grid(chunks, B * aa.H);
@@ -775,7 +786,10 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (hipSetDevice(device) != hipSuccess) return bail(fail(ctx, TAMF_ERR_HIP, "hipSetDevice failed"));
   {
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g_wg_slots = 2 * cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
+      TAMF_LAUNCH_LOCK;
+      g_wg_slots_dev[device & 63] = 2 * cus;
+    }
   }
   hipError_t pe;
   {
@@ -819,6 +833,46 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
 
 static int retire_graph(tamf_ctx* ctx);
 
+// the members alloc_workspaces() fills: saved / restored as a unit by tamf_ctx_resize
+struct WorkspaceSet {
+  float *xs, *cobj, *X, *pstatic;
+  OperandBuf xs_op, h1_op, X_op, QK_op, Vt_op, A_op, H_op;
+  void *X_st, *xs_st;
+  int* tcur;
+  unsigned* status;
+  unsigned char* side_dev;
+  int* objnum_dev;
+  float2 *stat_att, *stat_ffn;
+  LoopParams* loop_params;
+  long Mmax;
+  int Bmax, Tmax;
+  std::vector<void*> ws_allocs;
+  std::vector<GuardRec> ws_guards;
+};
+static WorkspaceSet ws_take(tamf_ctx* c) {  // moves the workspace set out of the context (its lists of workspace allocations / guards become empty)
+  WorkspaceSet w{c->xs, c->cobj, c->X, c->pstatic, c->xs_op, c->h1_op, c->X_op, c->QK_op, c->Vt_op, c->A_op, c->H_op, c->X_st, c->xs_st, c->tcur,
+                 c->status, c->side_dev, c->objnum_dev, c->stat_att, c->stat_ffn, c->loop_params, c->Mmax, c->Bmax, c->Tmax, {}, {}};
+  w.ws_allocs.swap(c->ws_allocs);
+  for (const GuardRec& g : c->guards)
+    if (g.ws) w.ws_guards.push_back(g);
+  c->guards.erase(std::remove_if(c->guards.begin(), c->guards.end(), [](const GuardRec& g) { return g.ws; }), c->guards.end());
+  return w;
+}
+static void ws_put(tamf_ctx* c, WorkspaceSet& w) {
+  c->xs = w.xs; c->cobj = w.cobj; c->X = w.X; c->pstatic = w.pstatic;
+  c->xs_op = w.xs_op; c->h1_op = w.h1_op; c->X_op = w.X_op; c->QK_op = w.QK_op; c->Vt_op = w.Vt_op; c->A_op = w.A_op; c->H_op = w.H_op;
+  c->X_st = w.X_st; c->xs_st = w.xs_st; c->tcur = w.tcur; c->status = w.status; c->side_dev = w.side_dev; c->objnum_dev = w.objnum_dev;
+  c->stat_att = w.stat_att; c->stat_ffn = w.stat_ffn; c->loop_params = w.loop_params;
+  c->Mmax = w.Mmax; c->Bmax = w.Bmax; c->Tmax = w.Tmax;
+  c->ws_allocs.swap(w.ws_allocs);
+  c->guards.insert(c->guards.end(), w.ws_guards.begin(), w.ws_guards.end());
+}
+
+// Transactional: the new workspaces are allocated FIRST, beside the old ones; only when every allocation has succeeded
+// are the old ones freed.  On failure (the likely one: a larger batch that does not fit) the partial new set is freed, the old set -
+// pointers, dimensions, conditioning - is put back and the context keeps working at its old size; the captured graph is gone either
+// way (it holds the old pointers' kernels: harmless, but it is re-captured on the next loop).  The sticky status word travels with
+// the context: bits raised and not yet read survive the resize.
 extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_frames) {
   TAMF_LAUNCH_LOCK;
   if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
@@ -831,16 +885,25 @@ extern "C" int tamf_ctx_resize(tamf_ctx* ctx, int32_t max_batch, int32_t max_fra
   TRY(retire_graph(ctx));
   if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
   ctx->graph_key = GraphKey{};
-  for (void* p : ctx->ws_allocs) (void)hipFree(p);
-  ctx->ws_allocs.clear();
-  ctx->guards.erase(std::remove_if(ctx->guards.begin(), ctx->guards.end(), [](const GuardRec& g) { return g.ws; }), ctx->guards.end());
-  ctx->xs = ctx->cobj = ctx->X = ctx->pstatic = nullptr;
-  ctx->xs_op = ctx->h1_op = ctx->X_op = ctx->QK_op = ctx->Vt_op = ctx->A_op = ctx->H_op = OperandBuf{};
-  ctx->X_st = ctx->xs_st = nullptr;
-  ctx->stat_att = ctx->stat_ffn = nullptr;
+  WorkspaceSet old = ws_take(ctx);
+  int rc = alloc_workspaces(ctx, max_batch, max_frames);
+  if (rc == 0 && old.status && ctx->status &&
+      hipMemcpy(ctx->status, old.status, 16, hipMemcpyDeviceToDevice) != hipSuccess)
+    rc = fail(ctx, TAMF_ERR_HIP, "tamf_ctx_resize: carrying the status word over failed");
+  if (rc != 0) {
+    const std::string why = ctx->err;
+    WorkspaceSet part = ws_take(ctx);  // whatever alloc_workspaces got before it failed
+    for (void* p : part.ws_allocs) (void)hipFree(p);
+    ws_put(ctx, old);
+    ctx->alloc_ws = false;
+    ctx->err = "tamf_ctx_resize(" + std::to_string(max_batch) + ", " + std::to_string(max_frames) + ") failed, the context keeps its " +
+               std::to_string(ctx->Bmax) + " x " + std::to_string(ctx->Tmax) + " workspaces: " + why;
+    return rc;
+  }
+  for (void* p : old.ws_allocs) (void)hipFree(p);
   ctx->cond_set = false;
   ctx->B = ctx->T = ctx->S = ctx->Sp = ctx->Skp = ctx->M = 0;
-  return alloc_workspaces(ctx, max_batch, max_frames);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1190,7 +1253,7 @@ static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, i
   // one to ~ 6 clips: 32 x 64 tiles (4 waves, six stages) while they fit one workgroup per CU - half the L2 -> LDS fill per workgroup and K
   // interval of the 32 x 128 tile, which is what a one-clip FFN2 was left bound by: 19.1 -> 14.2 us (f16x3), 10.3 -> 7.3 (bf16), 46.9 -> 25.5
   // (f32); the step of one clip 434 -> 385 / 256 -> 226 / 900 -> 686 us (profiles/r05/small_batch_32x64_c37.txt; same bits)
-  if (!(g_sel & (1 | 16)) && ga.N % 64 == 0 && ((ga.M + 31) / 32) * (ga.N / 64) <= g_wg_slots / 2)
+  if (!(g_sel & (1 | 16)) && ga.N % 64 == 0 && ((ga.M + 31) / 32) * (ga.N / 64) <= wg_slots() / 2)
     return GemmDeepLaunch<Op, 32, 64, 6, EpiResid<Op>, 2, 2>::launch(ga, ep, st);
   {
     hipError_t e = hipSuccess;
@@ -1203,7 +1266,7 @@ static hipError_t launch_resid(const GemmArgs<Op>& ga, const EpiResid<Op>& ep, i
   // the whole-clip tiles win by a wide margin (b64_resid_deep_c34.txt).  Same K order per element: the same bits.
   if (!(g_sel & (1 | 16)) && Op::PREC != 0 && ga.N % 128 == 0) {
     const int t64 = ((ga.M + 63) / 64) * (ga.N / 128);
-    if (Op::SPLIT ? t64 * 4 <= g_wg_slots / 2 * 5 : t64 <= g_wg_slots) return GemmDeepLaunch<Op, 64, 128, 3, EpiResid<Op>>::launch(ga, ep, st);
+    if (Op::SPLIT ? t64 * 4 <= wg_slots() / 2 * 5 : t64 <= wg_slots()) return GemmDeepLaunch<Op, 64, 128, 3, EpiResid<Op>>::launch(ga, ep, st);
   }
   if (!(g_sel & 2)) {
     TAMF_CLIP_NSUB(Sp, {
@@ -1514,6 +1577,10 @@ extern "C" int tamf_test_set_guard_bytes(int64_t bytes) {
   return 0;
 }
 
+extern "C" int tamf_test_fail_alloc_after(int32_t n) {
+  g_fail_alloc_in.store(n);
+  return 0;
+}
 extern "C" int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset, int32_t nbytes) {
   if (!ctx || alloc_index < 0 || (size_t)alloc_index >= ctx->guards.size() || nbytes <= 0) return fail(ctx, TAMF_ERR_INVALID, "bad argument");
   const GuardRec& g = ctx->guards[alloc_index];

@@ -125,8 +125,16 @@ def check_deep(path, log=None):
             need = {(a_pw + w_pw) * (nstg - 2)} | ({(a_pw - 1 + w_pw) * (nstg - 2)} if a_rem else set())
             dma = sum(1 for l in body if l.strip().startswith("global_load_lds"))
             spill = any(l.strip().startswith("scratch_") for l in body)
-            ok = dma == want_dma and need <= waits and not spill
-            line = f"{'ok ' if ok else 'BAD'} {m.group(2):8s} {bm}x{bn} NSTG={nstg}: global_load_lds {dma} (expected {want_dma}), counted waits needed {sorted(need)}, seen {sorted(waits)}"
+            # the prologue's LDS-DMA stages must have landed at the first barrier: an s_waitcnt that waits for vmcnt(0) between the last
+            # prologue request (the (NSTG - 1)-th batch) and the first s_barrier
+            first_bar = next((k for k, l in enumerate(body) if l.strip().startswith("s_barrier")), len(body))
+            dma_idx = [k for k, l in enumerate(body) if l.strip().startswith("global_load_lds")]
+            pro_last = dma_idx[(nstg - 1) * (a_pw + w_pw) - 1] if len(dma_idx) >= (nstg - 1) * (a_pw + w_pw) else -1
+            pro_wait = pro_last >= 0 and pro_last < first_bar and any(
+                re.search(r"s_waitcnt\b.*vmcnt\(0\)", l) for l in body[pro_last:first_bar])
+            ok = dma == want_dma and need <= waits and not spill and pro_wait
+            line = (f"{'ok ' if ok else 'BAD'} {m.group(2):8s} {bm}x{bn} NSTG={nstg}: global_load_lds {dma} (expected {want_dma}), counted waits needed {sorted(need)}, "
+                    f"seen {sorted(waits)}, vmcnt(0) between the prologue's requests and the first barrier: {pro_wait}")
             if log:
                 log(line)
             if not ok:

@@ -162,5 +162,5 @@ def load_from(path: str) -> ctypes.CDLL:
 EXPORTS = [
     "tamf_ctx_create", "tamf_ctx_resize", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
     "tamf_set_schedule", "tamf_set_cond", "tamf_set_cond_ragged", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
-    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_refine_profile", "tamf_test_gemm", "tamf_test_gemm_resid", "tamf_test_attention", "tamf_test_philox", "tamf_test_set_guard_bytes", "tamf_test_check_guards", "tamf_test_poke", "tamf_bench_gemm", "tamf_bench_attention", "tamf_bench_mfma_rate", "tamf_set_gemm_tuning",
+    "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals", "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_refine_profile", "tamf_test_gemm", "tamf_test_gemm_resid", "tamf_test_attention", "tamf_test_philox", "tamf_test_set_guard_bytes", "tamf_test_check_guards", "tamf_test_poke", "tamf_test_fail_alloc_after", "tamf_bench_gemm", "tamf_bench_attention", "tamf_bench_mfma_rate", "tamf_set_gemm_tuning",
 ]

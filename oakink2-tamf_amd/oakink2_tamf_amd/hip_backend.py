@@ -66,6 +66,8 @@ def lib() -> ctypes.CDLL:
             L.tamf_test_set_guard_bytes.argtypes = [c_int64]
             L.tamf_test_check_guards.argtypes = [c_void_p, POINTER(c_int32)]
             L.tamf_test_poke.argtypes = [c_void_p, c_int32, c_int64, c_int32]
+        if hasattr(L, "tamf_test_fail_alloc_after"):
+            L.tamf_test_fail_alloc_after.argtypes = [c_int32]
         L.tamf_denoise.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
         L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]

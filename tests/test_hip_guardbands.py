@@ -126,3 +126,40 @@ def test_the_guard_bands_do_catch_an_overrun():
     with pytest.raises(TamfError, match=r"allocation #3 .* BELOW its start \(offsets -8 \.\. -1\)"):
         ctx.check_guards()
     ctx.close()
+
+
+def test_a_resize_that_runs_out_of_memory_leaves_the_context_working_at_its_old_size():
+    """tamf_ctx_resize used to free every workspace before allocating the new ones, so a failed allocation left the
+    context with dangling pointers behind enlarged dimensions.  Now it is transactional: with the k-th of its allocations failing
+    (every k, injected), the call reports TAMF_ERR_NOMEM, the old workspaces, conditioning and status word stay, the guard bands
+    are intact, the same evaluation gives the same bits, and a later resize that fits succeeds."""
+    from oracle import mdm_oracle as O
+    from oakink2_tamf_amd.hip_backend import TamfContext, TamfError, lib
+
+    arch = O.ARCH_TINY
+    a = dict(latent_dim=arch.latent_dim, ff_size=arch.ff_size, num_layers=arch.num_layers, num_heads=arch.num_heads)
+    ctx = TamfContext(a, 2, 16, precision="f16x3", device="cuda:0")
+    ctx.load_state_dict(O.det_state_dict(arch, tag="guard/t"))
+    i = _inputs(2, 16)
+    ctx.set_cond(i["text"], i["side"], i["shape"], i["emb"], i["traj"])
+    ref = ctx.denoise(i["x"], i["t"]).clone()
+    n_guard = ctx.check_guards()
+    for k in (0, 1, 5, 11, 17):  # the first, some in the middle, the last workspace allocation
+        assert lib().tamf_test_fail_alloc_after(k) == 0
+        with pytest.raises(TamfError, match=r"keeps its 2 x 16 workspaces.*injected"):
+            ctx.resize(8, 40)
+        assert lib().tamf_test_fail_alloc_after(-1) == 0
+        assert (ctx.max_batch, ctx.max_frames) == (2, 16)
+        assert ctx.check_guards() == n_guard
+        # conditioning and workspaces are the old ones: the same call, the same bits - and a batch beyond the old size is still refused
+        assert torch.equal(ctx.denoise(i["x"], i["t"]), ref)
+        j = _inputs(4, 16)
+        with pytest.raises(TamfError):
+            ctx.set_cond(j["text"], j["side"], j["shape"], j["emb"], j["traj"])
+        ctx.set_cond(i["text"], i["side"], i["shape"], i["emb"], i["traj"])
+    ctx.resize(4, 24)  # and one that fits goes through
+    j = _inputs(4, 24)
+    ctx.set_cond(j["text"], j["side"], j["shape"], j["emb"], j["traj"])
+    assert torch.isfinite(ctx.denoise(j["x"], j["t"])).all()
+    ctx.check_guards()
+    ctx.close()
