@@ -134,6 +134,12 @@ struct tamf_ctx {
   LoopParams* loop_params = nullptr;
   int sched_cap = 0;  // allocated length of c1 / c2 / sigma
   int graph_captures = 0, graph_launches_last_loop = 0;  // tamf_loop_stats
+#ifdef TAMF_BENCH
+  // overlap probe (selection bit 256, measurement builds only): see PingPong
+  std::vector<hipEvent_t> pp_ev;
+  long pp_count = 0;
+  bool pp_on = false;
+#endif
   int step_kernels = 0;
   // per-launch profiling (tamf_step_profile)
   bool prof_on = false;
@@ -297,6 +303,8 @@ static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = residual GEMMs of a few clips on the clip / 128 x 128 tiles too (no 32- / 64-row tiles), 64 = f32: QKV on the 128 x 128 tiles,
+// 256 = (-DTAMF_BENCH builds only) OVERLAP PROBE: the launches of a no-graph loop alternate between two streams with no data
+//       dependency enforced - garbage samples, the time is an upper bound of what removing the kernel boundaries could gain (PingPong),
 // 512 = streaming attention kernel in the 16-bit modes too,
 // 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds.
 // (Rounds 2 - 5 also had 16 (another meaning) / 256 / 2048 / 4096: the LayerNorm-fused 64 x d tile, the GEMM + LayerNorm-kernel form and the row-block kernel
@@ -826,6 +834,9 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+#ifdef TAMF_BENCH
+  for (hipEvent_t e : ctx->pp_ev) (void)hipEventDestroy(e);
+#endif
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (void* p : ctx->ws_allocs) (void)hipFree(p);
   delete ctx;
@@ -1243,6 +1254,32 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
 // ------------------------------------------------------------------------------------------------
 // one denoiser evaluation = the kernel sequence below (captured into a hipGraph by the sampling loop)
 // ------------------------------------------------------------------------------------------------
+#ifdef TAMF_BENCH
+// OVERLAP PROBE (measurement builds only; tamf_set_gemm_tuning selection bit 256; plain launches, no hipGraph).  What would a step gain
+// if launch k + 1 could start on the CUs that launch k has left, instead of behind the kernel boundary - the most that per-clip ready
+// flags / a persistent per-clip pipeline could recover?  The launches of the loop alternate between the caller's stream and the
+// context's second stream, and NOTHING enforces their data dependencies: the SAMPLES ARE GARBAGE, only the time means something, and
+// it is an upper bound (a real consumer waits for its producers' tiles; here it waits for nothing).  Order of dispatch is kept sane:
+// launch k becomes eligible when launch k - 2 (same stream) and launch k - 3 are complete - i.e. never before launch k - 1 became
+// eligible - so at most two launches share the chip, the older one placed first (gfx950 / ROCm 7.2 ignores hipExtAnyOrderLaunch on
+// one stream: tools/micro/anyorder.hip, profiles/r06/anyorder_c01.txt).
+struct PingPong {
+  tamf_ctx* c;
+  hipStream_t a, b;
+  hipStream_t next() {
+    if (!c->pp_on) return a;
+    const long k = c->pp_count++;
+    hipStream_t s = (k & 1) ? b : a;
+    const size_t NEV = c->pp_ev.size() - 1;  // (the last event is the loop's fork / join)
+    (void)hipEventRecord(c->pp_ev[k % NEV], s);  // fires when everything launched on s before launch k is complete
+    if (k > 0) (void)hipStreamWaitEvent(s, c->pp_ev[(k - 1) % NEV], 0);  // ... and launch k waits for what launch k - 1 waited for
+    return s;
+  }
+};
+#define TAMF_NEXT_STREAM pp_.next()
+#else
+#define TAMF_NEXT_STREAM st
+#endif
 // residual GEMM of the deferred-LayerNorm form (out-proj, FFN2; 16-bit modes): the clip's row parts where whole clips would fill at
 // most half of the CUs, whole-clip tiles where they fill at least half of their rounds' slots, 128 x 128 tiles for every other shape -
 // the same K order per element and the same statistics trees in all three, i.e. the same bits
@@ -1284,6 +1321,9 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   typedef typename Op::elem_t E;
   const int d = ctx->d, ff = ctx->ff, B = ctx->B, T = ctx->T, S = ctx->S, Sp = ctx->Sp, M = ctx->M, P = ctx->P;
   int nk = 0;
+#ifdef TAMF_BENCH
+  PingPong pp_{ctx, st, ctx->cap_stream};
+#endif
   // algorithmic FLOPs of the reference work each launch stands for (true S, not padded rows)
   const double BS = (double)B * S, BT = (double)B * T, dd = d, F = ctx->F;
   auto mark = [&](const char* name, double flops) {
@@ -1297,19 +1337,21 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     ctx->prof_flops.push_back(flops);
   };
   {  // input_merge.0 on [pose | (h2o)] with the hoisted object term, SiLU
+    hipStream_t sk = TAMF_NEXT_STREAM;
     GemmArgs<Op> ga{(const E*)ctx->xs_op.p, ctx->XK, (const E*)ctx->Wfused.p, ctx->XK, B * T, d, ctx->XK, 0};
     EpiBiasAct<Op> ep{nullptr, ctx->cobj, d, (E*)ctx->h1_op.p, d, ACT_SILU, {ctx->Wfused.inv_scale, ctx->status}};
-    HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+    HIPCHK(ctx, gemm128<Op>(ga, ep, sk));
     mark("gemm_input_merge0", BT * (2.0 * F * dd + 2.0 * dd * (ctx->arch.kind == TAMF_KIND_R ? 3 : 2) * dd +
                                     (ctx->arch.kind == TAMF_KIND_R ? 2.0 * ctx->arch.h2o_dim * dd : 0.0)));
   }
   {  // input_merge.2 + nan_to_num + positional rows -> token rows of X
+    hipStream_t sk = TAMF_NEXT_STREAM;
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
     // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
     EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_st, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off, {ctx->Wm2.inv_scale, ctx->status}};
     hipError_t es = hipSuccess;
-    if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
-    else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+    if (small_m_launch<Op>(ga, ep, sk, &es)) HIPCHK(ctx, es);
+    else HIPCHK(ctx, gemm128<Op>(ga, ep, sk));
     mark("gemm_input_merge2", BT * 2.0 * dd * dd + (ctx->has_t ? B * 4.0 * dd * dd : 0.0));
   }
   const float qscale = 1.4426950408889634f / sqrtf((float)ctx->hd);
@@ -1324,6 +1366,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
         const LnStats ln_in{l ? ctx->stat_ffn : nullptr, NB, inv_d, 1e-5f};  // the LayerNorm in front of the attention block (layer 0: none)
         const LnStats ln_ff{ctx->stat_att, NB, inv_d, 1e-5f};               // ... in front of the feed-forward block
         {
+          hipStream_t sk = TAMF_NEXT_STREAM;
           GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.Win.p, d, M, 3 * d, d, 0};
           bool on_clip = false;
           if constexpr (Op::PREC == 0) {  // f32: the Q | K columns and the V columns as two clip launches (see the other branch)
@@ -1332,13 +1375,14 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
                 if (ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::applies(B, Sp, 2 * d, d) && ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::applies(B, Sp, d, d)) {
                   EpiQK<Op, true> eq{w.c2_in, (E*)ctx->QK_op.p, d, qscale, ACT_NONE, {w.Win.inv_scale, ctx->status}, ln_in};
                   if (ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::applies(B, Sp, 2 * d, d))
-                    HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+                    HIPCHK(ctx, (ClipLaunch<Op, 4, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, sk)));
                   else
-                    HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, st)));
+                    HIPCHK(ctx, (ClipLaunch<Op, 2, EpiQK<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, 2 * d, d, eq, sk)));
                   const E* Wv = (const E*)((const char*)w.Win.p + (size_t)2 * d * d * Op::EB);
                   EpiVt<Op, true> ev{w.c2_in + 2 * d, (E*)ctx->Vt_op.p, ctx->H, ctx->hd, ctx->Skp, ACT_NONE, {w.Win.inv_scale, ctx->status}, ln_in};
                   mark("gemm_qk", BS * 2.0 * dd * 2 * dd);
-                  HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, st)));
+                  sk = TAMF_NEXT_STREAM;
+                  HIPCHK(ctx, (ClipLaunch<Op, 2, EpiVt<Op, true>, NS>::launch(nullptr, ga.A, d, Wv, d, B, Sp, d, d, ev, sk)));
                   mark("gemm_v", BS * 2.0 * dd * dd);
                   on_clip = true;
                 }
@@ -1348,45 +1392,49 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
           if (!on_clip) {
             EpiQKV<Op, true> ep{w.c2_in, (E*)ctx->QK_op.p, (E*)ctx->Vt_op.p, d, ctx->H, ctx->hd, Sp, ctx->Skp, qscale, {w.Win.inv_scale, ctx->status}, ln_in};
             hipError_t es = hipSuccess;
-            if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
-            else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+            if (small_m_launch<Op>(ga, ep, sk, &es)) HIPCHK(ctx, es);
+            else HIPCHK(ctx, gemm128<Op>(ga, ep, sk));
             mark("gemm_qkv", BS * 2.0 * dd * 3 * dd);
           }
         }
         {
+          hipStream_t sk = TAMF_NEXT_STREAM;
           AttnArgs<Op> aa{(const E*)ctx->QK_op.p, (const E*)ctx->Vt_op.p, (E*)ctx->A_op.p, S, Sp, ctx->Skp, d, ctx->H, 0};
-          HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, st));
+          HIPCHK(ctx, launch_attn<Op>(aa, B, ctx->hd, sk));
           mark("attention", 4.0 * B * (double)S * S * dd);
         }
         {
+          hipStream_t sk = TAMF_NEXT_STREAM;
           GemmArgs<Op> ga{(const E*)ctx->A_op.p, d, (const E*)w.Wout.p, d, M, d, d, 0};
           EpiResid<Op> ep{w.bb_att, w.g_att, ctx->X, (E*)ctx->X_st, d, ctx->stat_att, ACT_NONE, {w.Wout.inv_scale, ctx->status}, ln_in};
-          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, st));
+          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, sk));
           mark("gemm_outproj", BS * 2.0 * dd * dd);
         }
         {
+          hipStream_t sk = TAMF_NEXT_STREAM;
           GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)w.W1.p, d, M, ff, d, 0};
           EpiBiasAct<Op, true> ep{w.c2_ff, nullptr, 0, (E*)ctx->H_op.p, ff, ACT_GELU, {w.W1.inv_scale, ctx->status}, ln_ff};
           bool on_clip = false;
           if (!(g_sel & 8)) {
             TAMF_CLIP_NSUB(Sp, {
               if (ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::applies(B, Sp, ff, d)) {
-                HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, st)));
+                HIPCHK(ctx, (ClipLaunch<Op, 4, EpiBiasAct<Op, true>, NS>::launch(nullptr, ga.A, d, ga.W, d, B, Sp, ff, d, ep, sk)));
                 on_clip = true;
               }
             })
           }
           if (!on_clip) {
             hipError_t es = hipSuccess;
-            if (small_m_launch<Op>(ga, ep, st, &es)) HIPCHK(ctx, es);
-            else HIPCHK(ctx, gemm128<Op>(ga, ep, st));
+            if (small_m_launch<Op>(ga, ep, sk, &es)) HIPCHK(ctx, es);
+            else HIPCHK(ctx, gemm128<Op>(ga, ep, sk));
           }
           mark("gemm_ffn1_gelu", BS * 2.0 * dd * ff);
         }
         {
+          hipStream_t sk = TAMF_NEXT_STREAM;
           GemmArgs<Op> ga{(const E*)ctx->H_op.p, ff, (const E*)w.W2.p, ff, M, d, ff, 0};
           EpiResid<Op> ep{w.bb_ffn, w.g_ffn, ctx->X, (E*)ctx->X_st, d, ctx->stat_ffn, ACT_NONE, {w.W2.inv_scale, ctx->status}, ln_ff};
-          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, st));
+          HIPCHK(ctx, launch_resid<Op>(ga, ep, B, Sp, sk));
           mark("gemm_ffn2", BS * 2.0 * dd * ff);
         }
       }
@@ -1394,12 +1442,13 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   }
   {
     // N = 128 is a single column tile: 64-row tiles (8 waves) double the workgroups that share the Philox-heavy epilogue
+    hipStream_t sk = TAMF_NEXT_STREAM;
     GemmArgs<Op> ga{(const E*)ctx->X_op.p, d, (const E*)ctx->Wf.p, d, M, ctx->XN, d, 0};
     EpiHead<Op> head = head_in;
     head.t_off = t_off;
     hipError_t es = hipSuccess;
-    if (small_m_launch<Op>(ga, head, st, &es)) HIPCHK(ctx, es);  // (a few clips per call)
-    else HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head, st)));
+    if (small_m_launch<Op>(ga, head, sk, &es)) HIPCHK(ctx, es);  // (a few clips per call)
+    else HIPCHK(ctx, (GemmLaunch<Op, 64, 128, EpiHead<Op>>::launch(ga, head, sk)));
     mark("gemm_head_ddpm", BT * 2.0 * dd * F);
   }
   ctx->step_kernels = nk;
@@ -1507,10 +1556,32 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
                      (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {
+#ifdef TAMF_BENCH
+    ctx->pp_on = (g_sel & 256) != 0;
+    if (ctx->pp_on) {  // the second stream starts behind the loop's set-up kernels
+      if (ctx->pp_ev.empty()) {
+        ctx->pp_ev.resize(64);
+        for (auto& e : ctx->pp_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      ctx->pp_count = 0;
+      HIPCHK(ctx, hipEventRecord(ctx->pp_ev[63], st));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->cap_stream, ctx->pp_ev[63], 0));
+    }
+#endif
     for (int i = 0; i < N; ++i) {
       TRY(enqueue_step<Op>(ctx, st, h));
+#ifdef TAMF_BENCH
+      if (ctx->pp_on) { PingPong pp_{ctx, st, ctx->cap_stream}; hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, pp_.next(), ctx->tcur, B, 1); continue; }
+#endif
       hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B, 1);
     }
+#ifdef TAMF_BENCH
+    if (ctx->pp_on) {  // join: the caller's stream continues behind both
+      HIPCHK(ctx, hipEventRecord(ctx->pp_ev[63], ctx->cap_stream));
+      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->pp_ev[63], 0));
+      ctx->pp_on = false;
+    }
+#endif
   } else {
     // G consecutive steps per graph (the largest divisor of N up to 16: 10 for N = 1000 -> 100 graph launches per loop);
     // the sequence is step-agnostic (device-side step counter) and seed-agnostic (LoopParams), so it is captured once per

@@ -541,6 +541,144 @@ def capture_stress_dc():
                  sd_fn=O.det_state_dict_stress_dc, cond_fn=O.det_cond_stress)
 
 
+# --------------------------------------------------------------------------------------
+# Weights that have been through the reference's own optimiser step
+# --------------------------------------------------------------------------------------
+TRAINED = {
+    # name: (arch, training steps, batch, frames)
+    "trained_tiny": (O.ARCH_TINY, 4000, 32, 40),
+    "trained_hd128": (O.Arch(latent_dim=128, ff_size=256, num_layers=2, num_heads=1), 4000, 32, 40),  # head dim 128, as arch_mdm_l
+}
+
+
+def trained_weights_path(name: str) -> str:
+    return os.path.join(OUT_DIR, f"{name}_weights.npz")
+
+
+def trained_state_dict(arch: O.Arch, tag: str = "") -> dict:
+    """sd_fn of capture_forward / capture_loop: the stored weights of the fixture the tag names (tag = '<name>.../w')."""
+    name = next(n for n in TRAINED if tag.startswith(n))
+    with np.load(trained_weights_path(name)) as z:
+        sd = {k: torch.from_numpy(z[k].copy()) for k in z.files if not k.startswith("meta/")}
+    pe = O.positional_table(arch.latent_dim).unsqueeze(1).contiguous()  # (buffers, not parameters: regenerated, not stored)
+    for k in O.state_dict_spec(arch):
+        if k.endswith(".pe"):
+            sd[k] = pe
+    return sd
+
+
+def _smooth_motion_batch(gen: torch.Generator, arch: O.Arch, B: int, T: int):
+    """Synthetic 'smooth motion' clips and their conditioning, with the magnitudes of the real data: a pose trajectory
+    x0 = offset(cond) + a few low harmonics over the clip, CLIP features of norm 10, object trajectories [metres | unit rot6d].
+    The pose offset depends LINEARLY on the conditioning (text, shape, object embedding, hand side) through fixed mixing matrices, so
+    the denoiser has something to learn from every prefix token."""
+    F = arch.input_dim
+    te = torch.randn(B, arch.clip_dim, generator=gen)
+    te = te / te.norm(dim=-1, keepdim=True) * 10.0
+    shape = torch.randn(B, 1, arch.hand_shape_dim, generator=gen).repeat(1, T, 1).contiguous()
+    oe = torch.randn(B, 2, arch.obj_embed_dim, generator=gen)
+    raw = torch.randn(B, 2, T, 12, generator=gen)
+    # smooth object translation: a random walk scaled to decimetres
+    tsl = 0.02 * torch.cumsum(raw[..., :3], dim=2) + 0.3 * torch.randn(B, 2, 1, 3, generator=gen)
+    a1, a2 = raw[:, :, :1, 3:6].expand(-1, -1, T, -1), raw[:, :, :1, 6:9].expand(-1, -1, T, -1)
+    b1 = a1 / a1.norm(dim=-1, keepdim=True)
+    a2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = a2 / a2.norm(dim=-1, keepdim=True)
+    rot6d = torch.stack([b1, b2], dim=-1).reshape(B, 2, T, 6)
+    traj = torch.cat([tsl, rot6d], dim=-1).contiguous()
+    side = ["rh" if int(v) == 0 else "lh" for v in torch.randint(0, 2, (B,), generator=gen)]
+    mix = torch.Generator().manual_seed(777)  # the fixed "world": how conditioning maps to motion
+    M_t = torch.randn(arch.clip_dim, F, generator=mix) * (0.6 / 10.0 / arch.clip_dim ** 0.5) * 10.0
+    M_s = torch.randn(arch.hand_shape_dim, F, generator=mix) * (0.4 / arch.hand_shape_dim ** 0.5)
+    M_o = torch.randn(arch.obj_embed_dim, F, generator=mix) * (0.4 / arch.obj_embed_dim ** 0.5)
+    v_side = torch.randn(F, generator=mix) * 0.3
+    off = te @ M_t / 10.0 + shape[:, 0] @ M_s + oe.mean(dim=1) @ M_o
+    off = off + torch.tensor([1.0 if h == "lh" else -1.0 for h in side])[:, None] * v_side
+    tt = torch.arange(T, dtype=torch.float32) / T
+    x = off[:, None, :].expand(B, T, F).clone()
+    for k in (1, 2, 3):
+        amp = torch.randn(B, 1, F, generator=gen) * (0.35 / k)
+        ph = torch.rand(B, 1, F, generator=gen) * 6.2831853
+        x = x + amp * torch.sin(6.2831853 * k * tt[None, :, None] + ph)
+    x = x + 0.5 * tsl.mean(dim=1).repeat(1, 1, F // 3)[..., :F]  # the hand follows the objects
+    cond = {"text_embedding": te, "hand_side": side, "shape": shape, "obj_embedding": oe, "obj_traj": traj}
+    return x.contiguous(), cond
+
+
+def capture_trained(name: str):
+    """Train the REFERENCE module with the REFERENCE's own training step - GaussianDiffusion.training_losses
+    (model/diffusion/gaussian_diffusion.py:1106-1188: q_sample + masked MSE on the x0 prediction), the uniform schedule sampler, AdamW
+    lr 1e-4 / weight decay 0 and per-parameter gradient clipping clip_gradient(optimizer, 0.1, 2.0) exactly as launch/train.py:462-533
+    runs it (model.train(): dropout 0.1 active) - on synthetic smooth motions, and store the resulting state dict.  Not reproduced:
+    the MANO-based extra loss (InteractionSegmentExtraLoss needs manotorch + licence-gated assets: loss_callback=None) and DDP.
+    The point is not motion quality: these are weights an optimiser produced - weight / LayerNorm statistics no hand-made recipe of
+    oracle/mdm_oracle.py imitates - for the fp32-tolerance gates of the HIP path to be measured on."""
+    from oakink2_tamf.model.diffusion_util import create_gaussian_diffusion
+    from oakink2_tamf.model.diffusion.resample import create_named_schedule_sampler
+    from oakink2_tamf.util.net_util import clip_gradient
+
+    arch, steps, B, T = TRAINED[name]
+    torch.manual_seed(20261004)
+    sd0 = O.det_state_dict(arch, tag=f"{name}/init")
+    m = _ref_model(arch, sd0)
+    for p_ in m.clip_model.parameters():
+        p_.requires_grad_(False)
+    diffusion = create_gaussian_diffusion(diffusion_steps=1000, noise_schedule="cosine")
+    sampler = create_named_schedule_sampler(name="uniform", diffusion=diffusion)
+    params = [p_ for n_, p_ in m.named_parameters() if not n_.startswith("clip_model")]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0)
+    gen = torch.Generator().manual_seed(1)
+    dev = torch.device("cpu")
+    losses = []
+    import time as _t
+
+    t0 = _t.time()
+    for it in range(steps):
+        opt.zero_grad()
+        m.train()
+        x, cond = _smooth_motion_batch(gen, arch, B, T)
+        batch = _ref_batch(cond, m)
+        batch["mask"] = torch.ones(B, T)
+        t, weights = sampler.sample(B, dev)
+        x_start = x.unsqueeze(3).permute(0, 2, 3, 1)  # (bs, in_dim, 1, seqlen), launch/train.py:519-521
+        loss_store, _ = diffusion.training_losses(m, x_start, t, model_kwargs={"batch": batch}, loss_callback=None)
+        loss = (loss_store["loss"] * weights).mean()
+        loss.backward()
+        clip_gradient(opt, 0.1, 2.0)
+        opt.step()
+        losses.append(float(loss))
+        if it % 250 == 0 or it == steps - 1:
+            print(f"train {name}: step {it:5d} loss {sum(losses[-50:]) / len(losses[-50:]):.4f}  ({_t.time() - t0:.0f} s)", flush=True)
+    m.eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("clip_model")}
+    spec = O.state_dict_spec(arch)
+    assert set(sd) >= set(spec), set(spec) - set(sd)
+    out = {k: sd[k].numpy() for k in spec if not k.endswith(".pe")}
+    moved = max(float((sd[k] - sd0[k]).abs().max()) for k in spec if not k.endswith(".pe"))
+    out["meta/steps"] = np.int64(steps)
+    out["meta/loss_first_last"] = np.array([sum(losses[:50]) / 50, sum(losses[-50:]) / 50])
+    out["meta/max_weight_change"] = np.float64(moved)
+    print(f"train {name}: loss {out['meta/loss_first_last'][0]:.4f} -> {out['meta/loss_first_last'][1]:.4f}, largest weight change {moved:.3f}")
+    np.savez_compressed(trained_weights_path(name), **out)
+
+
+def trained_cond(B: int, T: int, nobj: int = 2, tag: str = "c0", arch: O.Arch = O.ARCH_TINY):
+    """cond_fn of the trained fixtures: conditioning drawn like the training data's (seeded by the tag)."""
+    seed = int.from_bytes(tag.encode()[:8].ljust(8, b"\0"), "little") % (2 ** 31)
+    _, cond = _smooth_motion_batch(torch.Generator().manual_seed(seed), arch, B, T)
+    assert nobj == 2
+    return cond
+
+
+def capture_trained_all():
+    for name, (arch, steps, B, T) in TRAINED.items():
+        if not os.path.exists(trained_weights_path(name)) or os.environ.get("TAMF_RETRAIN"):
+            capture_trained(name)
+        capture_forward(name, arch, B=4, T=40, ts=[0, 1, 500, 999], sd_fn=trained_state_dict, cond_fn=trained_cond)
+        capture_loop(f"{name}_b2_t40_1000", arch, B=2, T=40, steps=1000, store_noise=False, dump_steps=[0, 499, 998, 999],
+                     sd_fn=trained_state_dict, cond_fn=trained_cond)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -568,6 +706,7 @@ def main():
     capture_loop_arch_mdm_1000()
     capture_stress()
     capture_stress_dc()
+    capture_trained_all()
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()
