@@ -859,6 +859,8 @@ def main(argv=None, sampler_factory=None):
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": dom["tflops"] / peak,
+            # the mode's own ceiling: three MFMAs per product in the split modes, i.e. at most a third of the 16-bit peak (= frac elsewhere)
+            "frac_of_split_ceiling": dom["tflops"] * MFMA_PER_PRODUCT[dtype] / peak,
             "mfma_sustained": sus,  # informational: `peak` above stays the nominal figure of MI355X_MICROARCH.md
             "mfma_issue_frac_of_sustained": dom["tflops"] * MFMA_PER_PRODUCT[dtype] / sus["value"] if sus["value"] > 0 else None,
             "traffic": hbm_traffic(dtype, dom["kernel"], B, T)[0],

@@ -20,6 +20,9 @@
 #include "tamf_gemm.h"
 #include "tamf_gemm_clip.h"
 #include "tamf_gemm_deep.h"
+#if defined(TAMF_BENCH) && !defined(TAMF_OVERLAP_PROBE)
+#define TAMF_OVERLAP_PROBE  // (-DTAMF_OVERLAP_PROBE alone: the probe without the ablation code of -DTAMF_BENCH, which spills in some bf16 / f32 instantiations)
+#endif
 #ifdef TAMF_BENCH  // the row-block LayerNorm GEMM of round 4 (measured, not faster: DESIGN.md): an A/B partner of the measurement builds only
 #endif
 #include "tamf_geom.h"
@@ -134,7 +137,7 @@ struct tamf_ctx {
   LoopParams* loop_params = nullptr;
   int sched_cap = 0;  // allocated length of c1 / c2 / sigma
   int graph_captures = 0, graph_launches_last_loop = 0;  // tamf_loop_stats
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
   // overlap probe (selection bit 256, measurement builds only): see PingPong
   std::vector<hipEvent_t> pp_ev;
   long pp_count = 0;
@@ -303,7 +306,7 @@ static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = residual GEMMs of a few clips on the clip / 128 x 128 tiles too (no 32- / 64-row tiles), 64 = f32: QKV on the 128 x 128 tiles,
-// 256 = (-DTAMF_BENCH builds only) OVERLAP PROBE: the launches of a no-graph loop alternate between two streams with no data
+// 256 = (-DTAMF_OVERLAP_PROBE / -DTAMF_BENCH builds only) OVERLAP PROBE: the launches of a no-graph loop alternate between two streams with no data
 //       dependency enforced - garbage samples, the time is an upper bound of what removing the kernel boundaries could gain (PingPong),
 // 512 = streaming attention kernel in the 16-bit modes too,
 // 1024 = clip tiles from 50 % (not 74 %) of the workgroup slots of their rounds.
@@ -834,7 +837,7 @@ extern "C" void tamf_ctx_destroy(tamf_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
   for (hipEvent_t e : ctx->pp_ev) (void)hipEventDestroy(e);
 #endif
   for (void* p : ctx->allocs) (void)hipFree(p);
@@ -1254,8 +1257,8 @@ extern "C" int tamf_set_cond_ragged(tamf_ctx* ctx, int32_t B, int32_t T, int32_t
 // ------------------------------------------------------------------------------------------------
 // one denoiser evaluation = the kernel sequence below (captured into a hipGraph by the sampling loop)
 // ------------------------------------------------------------------------------------------------
-#ifdef TAMF_BENCH
-// OVERLAP PROBE (measurement builds only; tamf_set_gemm_tuning selection bit 256; plain launches, no hipGraph).  What would a step gain
+#ifdef TAMF_OVERLAP_PROBE
+// OVERLAP PROBE (-DTAMF_OVERLAP_PROBE measurement builds only; tamf_set_gemm_tuning selection bit 256; plain launches, no hipGraph).  What would a step gain
 // if launch k + 1 could start on the CUs that launch k has left, instead of behind the kernel boundary - the most that per-clip ready
 // flags / a persistent per-clip pipeline could recover?  The launches of the loop alternate between the caller's stream and the
 // context's second stream, and NOTHING enforces their data dependencies: the SAMPLES ARE GARBAGE, only the time means something, and
@@ -1321,7 +1324,7 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
   typedef typename Op::elem_t E;
   const int d = ctx->d, ff = ctx->ff, B = ctx->B, T = ctx->T, S = ctx->S, Sp = ctx->Sp, M = ctx->M, P = ctx->P;
   int nk = 0;
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
   PingPong pp_{ctx, st, ctx->cap_stream};
 #endif
   // algorithmic FLOPs of the reference work each launch stands for (true S, not padded rows)
@@ -1556,7 +1559,7 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
                      (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
     ctx->pp_on = (g_sel & 256) != 0;
     if (ctx->pp_on) {  // the second stream starts behind the loop's set-up kernels
       if (ctx->pp_ev.empty()) {
@@ -1570,12 +1573,12 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
 #endif
     for (int i = 0; i < N; ++i) {
       TRY(enqueue_step<Op>(ctx, st, h));
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
       if (ctx->pp_on) { PingPong pp_{ctx, st, ctx->cap_stream}; hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, pp_.next(), ctx->tcur, B, 1); continue; }
 #endif
       hipLaunchKernelGGL(advance_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, B, 1);
     }
-#ifdef TAMF_BENCH
+#ifdef TAMF_OVERLAP_PROBE
     if (ctx->pp_on) {  // join: the caller's stream continues behind both
       HIPCHK(ctx, hipEventRecord(ctx->pp_ev[63], ctx->cap_stream));
       HIPCHK(ctx, hipStreamWaitEvent(st, ctx->pp_ev[63], 0));

@@ -38,6 +38,37 @@ def golden_cond(fix):
     }
 
 
+TRAINED_ARCHS = {  # fixtures whose weights came out of the reference's own training step (oracle/capture_golden.py:capture_trained)
+    "trained_tiny": dict(latent_dim=128, ff_size=256, num_layers=2, num_heads=2),
+    "trained_hd128": dict(latent_dim=128, ff_size=256, num_layers=2, num_heads=1),  # head dim 128, as arch_mdm_l
+}
+
+
+def trained_arch(name):
+    from oracle import mdm_oracle as O
+
+    return O.Arch(**TRAINED_ARCHS[name])
+
+
+def load_trained_sd(name):
+    """state dict of a trained fixture: tests/golden/<name>_weights.npz holds the parameters; the positional tables are buffers
+    (never trained) and are regenerated"""
+    import torch
+
+    from oracle import mdm_oracle as O
+
+    arch = trained_arch(name)
+    with np.load(os.path.join(GOLDEN, f"{name}_weights.npz")) as z:
+        sd = {k: torch.from_numpy(z[k].copy()) for k in z.files if not k.startswith("meta/")}
+        meta = {k[5:]: z[k] for k in z.files if k.startswith("meta/")}
+    pe = O.positional_table(arch.latent_dim).unsqueeze(1).contiguous()
+    for k in O.state_dict_spec(arch):
+        if k.endswith(".pe"):
+            sd[k] = pe
+    assert set(sd) == set(O.state_dict_spec(arch))
+    return sd, meta
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cond, load_golden
+from conftest import TRAINED_ARCHS, golden_cond, load_golden, load_trained_sd, trained_arch
 
 pytestmark = pytest.mark.gpu
 
@@ -284,6 +284,65 @@ def test_stress_loop50_golden(kind, prec):
         worst = max(worst, float(np.abs(dump[int(s)] - ref).max() / max(1.0, np.abs(ref).max())))
     print(f"stress 50-step loop[{kind}, {prec}] T=160: max|err| / max|ref| = {worst:.3e}")
     assert worst < LOOP_TOL[prec], (kind, prec, worst)
+    if prec == "f16x3":
+        assert ctx.status_flags() == 0
+    ctx.close()
+
+
+# ---- trained fixtures (round 6): weights an optimiser produced --------------------------------------------------------
+# The reference's own training step (GaussianDiffusion.training_losses + AdamW + its gradient clipping, launch/train.py:462-533) run for a
+# few thousand steps on synthetic smooth motions in the build container (oracle/capture_golden.py:capture_trained); reference outputs of
+# one evaluation (t = 0, 1, 500, 999 and mixed) and of the 1000-step loop with those weights.  Gates as everywhere, relative to
+# max |ref| where that exceeds 1; the fp16 range flag must stay clear (no fallback to f32 was needed).
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", list(TRAINED_ARCHS))
+def test_trained_forward_golden(name, prec):
+    fix = load_golden(f"forward_{name}.npz")
+    arch = trained_arch(name)
+    sd, _ = load_trained_sd(name)
+    cond = golden_cond(fix)
+    x = torch.from_numpy(fix["x"])
+    B, _, _, T = x.shape
+    ctx = _make_ctx(arch, sd, B, T, prec)
+    _set_cond(ctx, cond)
+    worst = 0.0
+    for t in list(fix["ts"]) + ["mixed"]:
+        tt = torch.from_numpy(fix["ts_mixed"]) if t == "mixed" else torch.full((B,), int(t), dtype=torch.long)
+        ref = fix["out/mixed"] if t == "mixed" else fix[f"out/t{int(t)}"]
+        out = ctx.denoise(x, tt).cpu().numpy()
+        assert np.isfinite(out).all()
+        worst = max(worst, float(np.abs(out - ref).max() / max(1.0, np.abs(ref).max())))
+    print(f"trained forward[{name}, {prec}]: max|err| / max(1, |ref|max) = {worst:.3e}")
+    assert worst < FWD_TOL[prec], (name, prec, worst)
+    if prec == "f16x3":
+        assert ctx.status_flags() == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", list(TRAINED_ARCHS))
+def test_trained_loop_1000(name, prec):
+    from oracle import det
+
+    lname = f"{name}_b2_t40_1000"
+    fix = load_golden(f"loop_{lname}.npz")
+    arch = trained_arch(name)
+    sd, _ = load_trained_sd(name)
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 40)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(f"{lname}/eps", k), shape) for k in range(1001)]))
+    ctx = _make_ctx(arch, sd, 2, 40, prec, n_steps=1000)
+    _set_cond(ctx, cond)
+    out, dump = ctx.sample_loop(noise=draws, dump=True)
+    worst = 0.0
+    for s_ in fix["dump_steps"]:
+        ref = fix[f"dump/{int(s_)}"]
+        worst = max(worst, float(np.abs(dump[int(s_)].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())))
+    print(f"trained 1000-step loop[{name}, {prec}]: max|err| / max(1, |ref|max) = {worst:.3e}")
+    assert torch.isfinite(out).all()
+    assert worst < LOOP_TOL[prec], (name, prec, worst)
     if prec == "f16x3":
         assert ctx.status_flags() == 0
     ctx.close()

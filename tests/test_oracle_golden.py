@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cond, load_golden
+from conftest import TRAINED_ARCHS, golden_cond, load_golden, load_trained_sd, trained_arch
 from oracle import det
 from oracle import mdm_oracle as O
 
@@ -205,3 +205,50 @@ def test_stress_loop50_matches_reference(kind):
     for s in fix["dump_steps"]:
         ref = fix[f"dump/{int(s)}"]
         assert np.abs(dump[int(s)].numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), (kind, int(s))
+
+
+# ---- weights that have been through the reference's own training step (round 6) --------------------------------------
+# oracle/capture_golden.py:capture_trained runs GaussianDiffusion.training_losses (gaussian_diffusion.py:1106-1188) + AdamW + the
+# reference's gradient clipping (launch/train.py:462-533) on synthetic smooth motions; the fixtures hold the resulting parameters and
+# the REFERENCE module's outputs with them.
+
+
+@pytest.mark.parametrize("name", list(TRAINED_ARCHS))
+def test_trained_weights_are_trained(name):
+    sd, meta = load_trained_sd(name)
+    assert int(meta["steps"]) >= 2000
+    first, last = meta["loss_first_last"]
+    assert last < 0.5 * first, (first, last)  # the optimiser did reduce the reference's own loss
+    assert float(meta["max_weight_change"]) > 0.05
+
+
+@pytest.mark.parametrize("name", list(TRAINED_ARCHS))
+def test_trained_forward_matches_reference(name):
+    fix = load_golden(f"forward_{name}.npz")
+    arch = trained_arch(name)
+    sd, _ = load_trained_sd(name)
+    cond = golden_cond(fix)
+    x = torch.from_numpy(fix["x"])
+    B = x.shape[0]
+    for t in fix["ts"]:
+        out = O.denoiser_forward(sd, arch, x, torch.full((B,), int(t), dtype=torch.long), cond)
+        ref = fix[f"out/t{int(t)}"]
+        np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    out = O.denoiser_forward(sd, arch, x, torch.from_numpy(fix["ts_mixed"]), cond)
+    np.testing.assert_allclose(out.numpy(), fix["out/mixed"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(fix["out/mixed"]).max())))
+
+
+@pytest.mark.parametrize("name", list(TRAINED_ARCHS))
+def test_trained_loop_1000(name):
+    lname = f"{name}_b2_t40_1000"
+    fix = load_golden(f"loop_{lname}.npz")
+    arch = trained_arch(name)
+    sd, _ = load_trained_sd(name)
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 40)
+    tab = O.make_tables(1000, "cosine")
+    dump = []
+    O.sample_loop(sd, arch, tab, cond, shape, lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{lname}/eps", k), shape)), dump=dump)
+    for s_ in fix["dump_steps"]:
+        ref = fix[f"dump/{int(s_)}"]
+        np.testing.assert_allclose(dump[int(s_)].numpy(), ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
