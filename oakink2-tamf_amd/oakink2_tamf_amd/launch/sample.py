@@ -291,6 +291,25 @@ def load_clips(cfg, known):
     return CacheDictClips(cfg)
 
 
+def count_clips(cfg, known) -> int:
+    """number of clips of the source, for the parent's worker split - without building the clip source where that is expensive (ADVICE
+    r5: the parent used to construct CacheDictClips, i.e. torch.load every <obj_id>.pt, only to read `.n`; every worker builds its own)"""
+    d = cfg["data"]
+    if known.synthetic or d.get("cond_npz"):
+        return load_clips(cfg, known).n
+    if not d.get("cache_dict_filepath"):
+        d["cache_dict_filepath"] = _abspath(DEFAULT_CACHE_DICT)
+    if not os.path.exists(d["cache_dict_filepath"]):
+        return load_clips(cfg, known).n  # (raises the explanatory SystemExit)
+    if not d.get("obj_embedding_prefix") or not os.path.isdir(d["obj_embedding_prefix"]):
+        return load_clips(cfg, known).n  # (raises, or fails on the missing directory, as a worker would)
+    from ..dataset.interaction_segment import check_cache_dict, load_cache_dict
+
+    cache = load_cache_dict(d["cache_dict_filepath"])
+    check_cache_dict(cache, d["cache_dict_filepath"])
+    return len(cache["interaction_segment_len_list"])
+
+
 def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, known):
     import torch
 
@@ -341,7 +360,7 @@ def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     ckpt_setup(cfg, argv=sys.argv[1:] if argv is None else argv)
     ckpt_opt(cfg)
-    n_clips = load_clips(cfg, known).n  # (also fails early, in the parent, on a missing cache / embedding / prompt)
+    n_clips = count_clips(cfg, known)  # (also fails early, in the parent, on a missing cache / embedding directory)
     import torch
     import torch.multiprocessing as mp
 

@@ -108,6 +108,16 @@ def load_clips(cfg):
     return GeneratedPoseReprSampleAdaptor(dataset, dirs)
 
 
+def max_sample_frames(clips) -> int:
+    """longest G sample of the clip source WITHOUT materialising its items (item i of the adaptor converts poses to rot6d and
+    stacks trajectories, embeddings and point clouds - the old max() over clips[i] built every item once here and once more in
+    unique_clips()): the adaptor holds the loaded .npy arrays, a --data.clips_pkl list is scanned as it is"""
+    arrays = getattr(clips, "pose_repr_map", None)
+    if arrays:
+        return max(int(np.asarray(a).shape[0]) for a in arrays.values())
+    return max(int(np.asarray(clips[i]["sample_pose_repr"]).shape[0]) for i in range(len(clips)))
+
+
 def unique_clips(clips) -> Iterator:
     """(sample_id, item) of the first clip of every `info`: the reverse segments repeat their forward twin's (:217-222)"""
     seen = set()
@@ -185,7 +195,7 @@ def main(argv=None):
     clips = load_clips(cfg)
     mc = cfg["model"]
     bs = max(1, int(cfg["runtime"].get("batch_size", 64)))
-    T_max = max(int(np.asarray(clips[i]["sample_pose_repr"]).shape[0]) for i in range(len(clips)))
+    T_max = max_sample_frames(clips)
     model = SegmentRefineModel(cfg["mano"].get("mano_path"), **mc, use_pc=True, precision=known.precision, max_batch=min(bs, len(clips)),
                                max_frames=T_max, mano_layer_rh=mano[0], mano_layer_lh=mano[1], per_clip_object_mean=True).to(device)
     wpath = cfg["debug"].get("model_weight_filepath")
