@@ -2,6 +2,9 @@
 // step-invariant conditioning precompute, the per-step kernel sequence and its hipGraph replay loop.
 // gfx950 (MI355X) only.
 #include "../../include/tamf_hip.h"
+#ifdef TAMF_TEST_HOOKS
+#include "../../include/tamf_hip_test.h"
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -1645,16 +1648,21 @@ extern "C" int tamf_get_status_flags(tamf_ctx* ctx, uint32_t* flags, int32_t cle
   return 0;
 }
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_set_guard_bytes(int64_t bytes) {
   if (bytes < 0 || bytes > (1 << 20) || bytes % 256) return fail(nullptr, TAMF_ERR_INVALID, "guard bytes must be a multiple of 256 in [0, 1 MiB]");
   g_guard_bytes.store((size_t)bytes);
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_fail_alloc_after(int32_t n) {
   g_fail_alloc_in.store(n);
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset, int32_t nbytes) {
   if (!ctx || alloc_index < 0 || (size_t)alloc_index >= ctx->guards.size() || nbytes <= 0) return fail(ctx, TAMF_ERR_INVALID, "bad argument");
   const GuardRec& g = ctx->guards[alloc_index];
@@ -1663,7 +1671,9 @@ extern "C" int tamf_test_poke(tamf_ctx* ctx, int32_t alloc_index, int64_t offset
   HIPCHK(ctx, hipMemset(g.base + g.guard + offset, 0, nbytes));
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_check_guards(tamf_ctx* ctx, int32_t* n_checked) {
   if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1698,6 +1708,7 @@ extern "C" int tamf_test_check_guards(tamf_ctx* ctx, int32_t* n_checked) {
   if (bad) return fail(ctx, TAMF_ERR_STATE, "out-of-bounds device stores: " + report);
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
 extern "C" int tamf_step_kernel_count(const tamf_ctx* ctx) { return ctx ? ctx->step_kernels : 0; }
 
@@ -1867,6 +1878,7 @@ static int test_gemm_impl(int M, int N, int K, const float* a, const float* w, c
   return 0;
 }
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
                               const float* bias_dev, int32_t act, float* c_dev, void* stream) {
   TAMF_LAUNCH_LOCK;
@@ -1876,7 +1888,9 @@ extern "C" int tamf_test_gemm(int32_t precision, int32_t M, int32_t N, int32_t K
   TAMF_WITH_OP(precision, return test_gemm_impl<Op>(M, N, K, a_dev, w_dev, bias_dev, act, c_dev, nullptr, nullptr, nullptr, false, st));
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_gemm_resid(int32_t precision, int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev,
                                     const float* bb_dev, const float* gamma_dev, const float* stats_in_dev, float* x_dev,
                                     float* stats_out_dev, void* stream) {
@@ -1889,6 +1903,7 @@ extern "C" int tamf_test_gemm_resid(int32_t precision, int32_t M, int32_t N, int
                                                     (float2*)stats_out_dev, true, st));
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
 template <class Op>
 static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* out, hipStream_t st) {
@@ -1918,6 +1933,7 @@ static int test_attn_impl(int B, int S, int H, int hd, const float* qkv, float* 
   return 0;
 }
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, const float* qkv_dev,
                                    float* out_dev, void* stream) {
   TAMF_LAUNCH_LOCK;
@@ -1927,6 +1943,7 @@ extern "C" int tamf_test_attention(int32_t precision, int32_t B, int32_t S, int3
   TAMF_WITH_OP(precision, return test_attn_impl<Op>(B, S, H, hd, qkv_dev, out_dev, st));
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
 // random operand fill for the kernel benchmarks (values in [-1, 1))
 template <class Op>
@@ -2053,6 +2070,7 @@ static int bench_attn_impl(int B, int S, int H, int hd, int iters, int abl, floa
   return 0;
 }
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int32_t H, int32_t hd, int32_t iters, int32_t abl,
                                     int32_t tuning, float* ms_out, void* stream) {
   TAMF_LAUNCH_LOCK;
@@ -2066,7 +2084,9 @@ extern "C" int tamf_bench_attention(int32_t precision, int32_t B, int32_t S, int
   g_sel = saved_sel;
   return rc;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tflops_out, float* mhz_out, void* stream) {
   if (precision < 0 || precision > TAMF_PREC_F16X3 || millis <= 0 || millis > 20000 || !tflops_out) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -2110,7 +2130,9 @@ extern "C" int tamf_bench_mfma_rate(int32_t precision, int32_t millis, float* tf
   if (mhz_out) *mhz_out = (float)(mfmas / (cus * 4.0) * (precision == TAMF_PREC_F32 ? 32.0 : 16.0) / (ms * 1e-3) / 1e6);
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot, int32_t M, int32_t N, int32_t K,
                                int32_t iters, float* ms_out, void* stream) {
   TAMF_LAUNCH_LOCK;
@@ -2126,6 +2148,7 @@ extern "C" int tamf_bench_gemm(int32_t precision, int32_t epi_kind, int32_t krot
   g_sel = saved_sel;
   return rc;
 }
+#endif  // TAMF_TEST_HOOKS
 
 // ------------------------------------------------------------------------------------------------
 // geometry either side of the trunks
@@ -2212,6 +2235,7 @@ extern "C" int tamf_mesh_contains(const double* verts_dev, const int32_t* faces_
   return 0;
 }
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   TAMF_LAUNCH_LOCK;
   // low 20 bits: GemmArgs::krot bits (all ones = keep the per-kernel defaults); bits 20..30: kernel-selection overrides (g_sel).
@@ -2231,7 +2255,9 @@ extern "C" int tamf_set_gemm_tuning(int32_t krot) {
   g_krot = rot;
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t draw, int32_t B, int32_t n_feat, int32_t T,
                                 float* out_dev, void* stream) {
   if (B <= 0 || n_feat <= 0 || T <= 0 || !out_dev) return fail(nullptr, TAMF_ERR_INVALID, "bad argument");
@@ -2241,12 +2267,15 @@ extern "C" int tamf_test_philox(uint64_t seed, int64_t clip_id_base, int32_t dra
   if (e != hipSuccess) return fail(nullptr, TAMF_ERR_HIP, hipGetErrorString(e));
   return 0;
 }
+#endif  // TAMF_TEST_HOOKS
 
 #ifdef TAMF_TIMELINE
 // debug builds only (not part of include/tamf_hip.h): which = 0 GEMM (5 u64 per workgroup), 1 attention (4 u64)
+#ifdef TAMF_TEST_HOOKS  // (test / measurement hook: include/tamf_hip_test.h, libtamf_hip_hooks.so only)
 extern "C" int tamf_debug_timeline(int which, void* dst, size_t bytes) {
   if (which == 0) return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_ts), bytes, 0, hipMemcpyDeviceToHost);
   if (which == 2) return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_clip_ts), bytes, 0, hipMemcpyDeviceToHost);
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_ts), bytes, 0, hipMemcpyDeviceToHost);
 }
+#endif  // TAMF_TEST_HOOKS
 #endif

@@ -44,54 +44,81 @@ class _Arch(ctypes.Structure):
     ]
 
 
-_bound = False
+_bound = set()
+_use_hooks = False
 
 
-def lib() -> ctypes.CDLL:
-    global _bound
-    L = _lib.load()
-    if not _bound:
-        L.tamf_last_error.restype = c_char_p
-        L.tamf_last_error.argtypes = [c_void_p]
-        L.tamf_ctx_create.argtypes = [POINTER(_Arch), c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]
-        L.tamf_ctx_destroy.argtypes = [c_void_p]
-        L.tamf_ctx_destroy.restype = None
-        L.tamf_load_weight.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
-        L.tamf_finalize_weights.argtypes = [c_void_p, c_int32, c_void_p]
-        L.tamf_set_schedule.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
-        L.tamf_set_cond.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-        if hasattr(L, "tamf_set_cond_ragged"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
-            L.tamf_ctx_resize.argtypes = [c_void_p, c_int32, c_int32]
-            L.tamf_set_cond_ragged.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-            L.tamf_test_set_guard_bytes.argtypes = [c_int64]
-            L.tamf_test_check_guards.argtypes = [c_void_p, POINTER(c_int32)]
-            L.tamf_test_poke.argtypes = [c_void_p, c_int32, c_int64, c_int32]
-        if hasattr(L, "tamf_test_fail_alloc_after"):
-            L.tamf_test_fail_alloc_after.argtypes = [c_int32]
-        L.tamf_denoise.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-        L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
-        L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
-        L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-        if hasattr(L, "tamf_get_status_flags"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
-            L.tamf_get_status_flags.argtypes = [c_void_p, POINTER(ctypes.c_uint32), c_int32, c_void_p]
-        L.tamf_step_kernel_count.argtypes = [c_void_p]
-        L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
-        L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
-        if hasattr(L, "tamf_refine_profile"):
-            L.tamf_refine_profile.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+def _bind(L: ctypes.CDLL) -> ctypes.CDLL:
+    """argtypes / restypes of whatever the library object exports (once per object)"""
+    if id(L) in _bound:
+        return L
+    L.tamf_last_error.restype = c_char_p
+    L.tamf_last_error.argtypes = [c_void_p]
+    L.tamf_ctx_create.argtypes = [POINTER(_Arch), c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+    L.tamf_ctx_destroy.argtypes = [c_void_p]
+    L.tamf_ctx_destroy.restype = None
+    L.tamf_load_weight.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
+    L.tamf_finalize_weights.argtypes = [c_void_p, c_int32, c_void_p]
+    L.tamf_set_schedule.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
+    L.tamf_set_cond.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    if hasattr(L, "tamf_set_cond_ragged"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
+        L.tamf_ctx_resize.argtypes = [c_void_p, c_int32, c_int32]
+        L.tamf_set_cond_ragged.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.tamf_denoise.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.tamf_ddpm_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
+    L.tamf_sample_loop.argtypes = [c_void_p, c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_int32, c_void_p]
+    L.tamf_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    if hasattr(L, "tamf_get_status_flags"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
+        L.tamf_get_status_flags.argtypes = [c_void_p, POINTER(ctypes.c_uint32), c_int32, c_void_p]
+    L.tamf_step_kernel_count.argtypes = [c_void_p]
+    L.tamf_loop_stats.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32)]
+    L.tamf_step_profile.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+    if hasattr(L, "tamf_refine_profile"):
+        L.tamf_refine_profile.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+    # include/tamf_hip_test.h: only libtamf_hip_hooks.so (and the A/B builds of tools/ab_build.sh) has these
+    if hasattr(L, "tamf_test_gemm"):
         L.tamf_test_gemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
-        L.tamf_test_gemm_resid.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
         L.tamf_test_attention.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
         L.tamf_test_philox.argtypes = [c_uint64, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]
-        if hasattr(L, "tamf_bench_mfma_rate"):
-            L.tamf_bench_mfma_rate.argtypes = [c_int32, c_int32, POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]
-        _bound = True
+        L.tamf_set_gemm_tuning.argtypes = [c_int32]
+    if hasattr(L, "tamf_test_gemm_resid"):
+        L.tamf_test_gemm_resid.argtypes = [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8
+    if hasattr(L, "tamf_test_set_guard_bytes"):
+        L.tamf_test_set_guard_bytes.argtypes = [c_int64]
+        L.tamf_test_check_guards.argtypes = [c_void_p, POINTER(c_int32)]
+        L.tamf_test_poke.argtypes = [c_void_p, c_int32, c_int64, c_int32]
+    if hasattr(L, "tamf_test_fail_alloc_after"):
+        L.tamf_test_fail_alloc_after.argtypes = [c_int32]
+    if hasattr(L, "tamf_bench_mfma_rate"):
+        L.tamf_bench_mfma_rate.argtypes = [c_int32, c_int32, POINTER(ctypes.c_float), POINTER(ctypes.c_float), c_void_p]
+    _bound.add(id(L))
     return L
 
 
+def hooks() -> ctypes.CDLL:
+    """libtamf_hip_hooks.so: the -DTAMF_TEST_HOOKS build of the same sources (include/tamf_hip_test.h) - tests/, tools/, bench.py's
+    register-only MFMA probe.  Never the product path."""
+    return _bind(_lib.load_hooks())
+
+
+def use_test_hooks(on: bool = True) -> None:
+    """tests/ and tools/ only: contexts created from now on (and `lib()`) go through libtamf_hip_hooks.so, whose process-global
+    switches - guard bands, allocation-failure injection, the kernel-selection word of tamf_set_gemm_tuning - then apply to them.
+    A context keeps the library it was created with."""
+    global _use_hooks
+    _use_hooks = bool(on)
+
+
+def lib() -> ctypes.CDLL:
+    """the library new contexts are created with: libtamf_hip.so - the drop-in surface, nothing else - unless a test or tool has
+    switched to the hooks build (use_test_hooks)"""
+    return hooks() if _use_hooks else _bind(_lib.load())
+
+
 def set_guard_bytes(n: int) -> None:
-    """Test hook: contexts created from now on pad every device allocation with n guard bytes at both ends (0 = off)."""
-    _check(lib().tamf_test_set_guard_bytes(int(n)), None)
+    """Test hook: contexts created from now on THROUGH THE HOOKS LIBRARY (use_test_hooks) pad every device allocation with n guard
+    bytes at both ends (0 = off)."""
+    _check(hooks().tamf_test_set_guard_bytes(int(n)), None, hooks())
 
 
 def hand_side_code(hs) -> int:
@@ -117,9 +144,9 @@ def _stream_ptr(device: torch.device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _check(rc: int, ctx=None):
+def _check(rc: int, ctx=None, L=None):
     if rc != 0:
-        msg = lib().tamf_last_error(ctx)
+        msg = (L or lib()).tamf_last_error(ctx)
         raise (TamfRangeError if rc == -6 else TamfError)(f"libtamf_hip error {rc}: {msg.decode() if msg else '?'}")
 
 
@@ -147,6 +174,7 @@ class TamfContext:
         synchronisation) and raise TamfRangeError when an activation left the fp16 range (f16x3 only).  The drop-in modules do
         their own check - with an f32 fallback - and leave this off; a raw context has no fallback."""
         self.device = require_gpu(device)
+        self._L = lib()  # the library this context lives in: libtamf_hip.so unless a test / tool switched to the hooks build
         self.precision = precision
         self.range_check = bool(range_check) and precision == "f16x3"
         self.kind = kind
@@ -172,12 +200,12 @@ class TamfContext:
         self.max_timesteps = 0
         self._keep = []
         with torch.cuda.device(self.device):
-            _check(lib().tamf_ctx_create(ctypes.byref(a), max_batch, max_frames, PRECISIONS[precision],
-                                         self.device.index, ctypes.byref(self._h)))
+            _check(self._L.tamf_ctx_create(ctypes.byref(a), max_batch, max_frames, PRECISIONS[precision],
+                                           self.device.index, ctypes.byref(self._h)), None, self._L)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            lib().tamf_ctx_destroy(self._h)
+            self._L.tamf_ctx_destroy(self._h)
             self._h = c_void_p()
 
     def __del__(self):  # pragma: no cover
@@ -192,16 +220,16 @@ class TamfContext:
         `pe[timesteps]` lookup accepts (sequence_pos_encoder.pe has 5000 rows).  strict_weight_range (f16x3): raise
         TamfRangeError when the library reports STATUS_F16_WEIGHT_RANGE - a tensor whose per-tensor scale is dominated by an
         outlier, so that its ordinary weights keep fewer than 22 significand bits (the modules then fall back to f32)."""
-        L = lib()
+        L = self._L
         self.max_timesteps = int(max_timesteps)
         for name, t in sd.items():
             if not isinstance(t, torch.Tensor) or name.startswith("clip_model."):
                 continue
             h = t.detach().to("cpu", torch.float32).contiguous()
             shape = (c_int64 * max(h.dim(), 1))(*(list(h.shape) or [1]))
-            _check(L.tamf_load_weight(self._h, name.encode(), c_void_p(h.data_ptr()), shape, max(h.dim(), 1)), self._h)
+            _check(L.tamf_load_weight(self._h, name.encode(), c_void_p(h.data_ptr()), shape, max(h.dim(), 1)), self._h, self._L)
         with torch.cuda.device(self.device):
-            _check(L.tamf_finalize_weights(self._h, int(max_timesteps), c_void_p(_stream_ptr(self.device))), self._h)
+            _check(L.tamf_finalize_weights(self._h, int(max_timesteps), c_void_p(_stream_ptr(self.device))), self._h, self._L)
         if strict_weight_range and self.precision == "f16x3" and (self.status_flags(clear=False) & STATUS_F16_WEIGHT_RANGE):
             note = L.tamf_last_error(self._h)
             raise TamfRangeError(note.decode() if note else "f16x3: a weight tensor's dynamic range exceeds the split-fp16 format")
@@ -212,7 +240,7 @@ class TamfContext:
         lv = np.ascontiguousarray(log_variance_clipped, dtype=np.float64)
         assert c1.shape == c2.shape == lv.shape and c1.ndim == 1
         self.n_steps = int(c1.shape[0])
-        _check(lib().tamf_set_schedule(self._h, self.n_steps, c1.ctypes.data_as(c_void_p), c2.ctypes.data_as(c_void_p),
+        _check(self._L.tamf_set_schedule(self._h, self.n_steps, c1.ctypes.data_as(c_void_p), c2.ctypes.data_as(c_void_p),
                                        lv.ctypes.data_as(c_void_p)), self._h)
 
     # -- conditioning -------------------------------------------------------------------------
@@ -234,15 +262,15 @@ class TamfContext:
             num_np = np.ascontiguousarray(torch.as_tensor(obj_num).cpu().numpy() if isinstance(obj_num, torch.Tensor) else obj_num, dtype=np.int32)
             if num_np.shape != (B,):
                 raise ValueError(f"obj_num must hold one count per clip: shape {num_np.shape} for B = {B}")
-        if num_np is None and not hasattr(lib(), "tamf_set_cond_ragged"):  # (an older A/B build loaded through _lib.load_from)
+        if num_np is None and not hasattr(self._L, "tamf_set_cond_ragged"):  # (an older A/B build loaded through _lib.load_from)
             with torch.cuda.device(dev):
-                _check(lib().tamf_set_cond(self._h, B, T, nobj, c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),
+                _check(self._L.tamf_set_cond(self._h, B, T, nobj, c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),
                                            c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()), c_void_p(ot.data_ptr()), c_void_p(_stream_ptr(dev))), self._h)
             self._keep = [te, sh, oe, ot]
             self.B, self.T = int(B), int(T)
             return
         with torch.cuda.device(dev):
-            _check(lib().tamf_set_cond_ragged(self._h, B, T, nobj, num_np.ctypes.data_as(c_void_p) if num_np is not None else c_void_p(0),
+            _check(self._L.tamf_set_cond_ragged(self._h, B, T, nobj, num_np.ctypes.data_as(c_void_p) if num_np is not None else c_void_p(0),
                                               c_void_p(te.data_ptr() if te is not None else 0), side_np.ctypes.data_as(c_void_p),
                                               c_void_p(sh.data_ptr()), c_void_p(oe.data_ptr()), c_void_p(ot.data_ptr()),
                                               c_void_p(_stream_ptr(dev))), self._h)
@@ -268,7 +296,7 @@ class TamfContext:
             raise IndexError(f"timestep {lo if lo < 0 else hi} outside the timestep-embedding table [0, {self.max_timesteps})")
         out = torch.empty_like(xd)
         with torch.cuda.device(dev):
-            _check(lib().tamf_denoise(self._h, c_void_p(xd.data_ptr()), c_void_p(td.data_ptr()), c_void_p(out.data_ptr()),
+            _check(self._L.tamf_denoise(self._h, c_void_p(xd.data_ptr()), c_void_p(td.data_ptr()), c_void_p(out.data_ptr()),
                                       c_void_p(_stream_ptr(dev))), self._h)
         self._raise_on_range()
         return out
@@ -279,7 +307,7 @@ class TamfContext:
         nz = _dev_f32(noise, dev) if noise is not None else None
         out = torch.empty_like(xt)
         with torch.cuda.device(dev):
-            _check(lib().tamf_ddpm_step(self._h, c_void_p(xt.data_ptr()), c_void_p(x0d.data_ptr()), int(t),
+            _check(self._L.tamf_ddpm_step(self._h, c_void_p(xt.data_ptr()), c_void_p(x0d.data_ptr()), int(t),
                                         c_void_p(nz.data_ptr() if nz is not None else 0), c_void_p(out.data_ptr()),
                                         xt.numel(), c_void_p(_stream_ptr(dev))), self._h)
         return out
@@ -298,7 +326,7 @@ class TamfContext:
             out = torch.empty(shape, device=dev, dtype=torch.float32)
         dmp = torch.empty((self.n_steps,) + shape, device=dev, dtype=torch.float32) if dump else None
         with torch.cuda.device(dev):
-            _check(lib().tamf_sample_loop(self._h, c_void_p(nz.data_ptr() if nz is not None else 0), int(seed) & (2**64 - 1),
+            _check(self._L.tamf_sample_loop(self._h, c_void_p(nz.data_ptr() if nz is not None else 0), int(seed) & (2**64 - 1),
                                           int(clip_id_base), c_void_p(out.data_ptr()),
                                           c_void_p(dmp.data_ptr() if dmp is not None else 0), 1 if use_graph else 0,
                                           c_void_p(_stream_ptr(dev))), self._h)
@@ -317,7 +345,7 @@ class TamfContext:
         current stream."""
         v = ctypes.c_uint32(0)
         with torch.cuda.device(self.device):
-            _check(lib().tamf_get_status_flags(self._h, ctypes.byref(v), 1 if clear else 0, c_void_p(_stream_ptr(self.device))),
+            _check(self._L.tamf_get_status_flags(self._h, ctypes.byref(v), 1 if clear else 0, c_void_p(_stream_ptr(self.device))),
                    self._h)
         return int(v.value)
 
@@ -325,7 +353,7 @@ class TamfContext:
         """Re-dimension the workspaces for (max_batch, max_frames); the uploaded weights and the schedule stay.  Conditioning must be
         set again."""
         with torch.cuda.device(self.device):
-            _check(lib().tamf_ctx_resize(self._h, int(max_batch), int(max_frames)), self._h)
+            _check(self._L.tamf_ctx_resize(self._h, int(max_batch), int(max_frames)), self._h, self._L)
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self.B = self.T = 0
         self._keep = []
@@ -334,7 +362,7 @@ class TamfContext:
         """Test hook: verify the guard bands around every device allocation of this context (set_guard_bytes() before it was
         created).  Raises TamfError naming the allocations a kernel wrote outside of; returns the number of guarded allocations."""
         n = c_int32(0)
-        _check(lib().tamf_test_check_guards(self._h, ctypes.byref(n)), self._h)
+        _check(self._L.tamf_test_check_guards(self._h, ctypes.byref(n)), self._h, self._L)
         return int(n.value)
 
     def refine(self, sample_pose_repr: torch.Tensor, h2o_dist: torch.Tensor) -> torch.Tensor:
@@ -344,7 +372,7 @@ class TamfContext:
         assert tuple(h2o.shape) == (self.B, self.T, self.h2o_dim)
         out = torch.empty_like(xin)
         with torch.cuda.device(dev):
-            _check(lib().tamf_refine(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()),
+            _check(self._L.tamf_refine(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()),
                                      c_void_p(_stream_ptr(dev))), self._h)
         self._raise_on_range()
         return out
@@ -352,12 +380,12 @@ class TamfContext:
     def loop_stats(self):
         """(graph captures so far, graph launches of the last sample_loop call)"""
         a, b = c_int32(), c_int32()
-        _check(lib().tamf_loop_stats(self._h, ctypes.byref(a), ctypes.byref(b)), self._h)
+        _check(self._L.tamf_loop_stats(self._h, ctypes.byref(a), ctypes.byref(b)), self._h, self._L)
         return int(a.value), int(b.value)
 
     @property
     def step_kernel_count(self) -> int:
-        return int(lib().tamf_step_kernel_count(self._h))
+        return int(self._L.tamf_step_kernel_count(self._h))
 
     def step_profile(self, max_n: int = 256):
         """[(name, ms, algorithmic_flops)] of one denoiser step, measured with HIP events on the launch stream."""
@@ -366,9 +394,9 @@ class TamfContext:
         fl = (c_double * max_n)()
         names = ctypes.create_string_buffer(max_n * 48)
         with torch.cuda.device(self.device):
-            n = lib().tamf_step_profile(self._h, max_n, ms, fl, names, c_void_p(_stream_ptr(self.device)))
+            n = self._L.tamf_step_profile(self._h, max_n, ms, fl, names, c_void_p(_stream_ptr(self.device)))
         if n < 0:
-            _check(n, self._h)
+            _check(n, self._h, self._L)
         out = []
         for i in range(n):
             nm = names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
@@ -384,10 +412,10 @@ class TamfContext:
         out = torch.empty_like(xin)
         ms, fl, names = (c_float * max_n)(), (c_double * max_n)(), ctypes.create_string_buffer(max_n * 48)
         with torch.cuda.device(dev):
-            n = lib().tamf_refine_profile(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()), max_n,
+            n = self._L.tamf_refine_profile(self._h, c_void_p(xin.data_ptr()), c_void_p(h2o.data_ptr()), c_void_p(out.data_ptr()), max_n,
                                           ms, fl, names, c_void_p(_stream_ptr(dev)))
         if n < 0:
-            _check(n, self._h)
+            _check(n, self._h, self._L)
         return [(names.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode(), float(ms[i]), float(fl[i])) for i in range(n)]
 
 
@@ -401,9 +429,9 @@ def test_gemm(precision: str, a: torch.Tensor, w: torch.Tensor, bias: Optional[t
     c = torch.empty((M, N), device=dev, dtype=torch.float32)
     a, w = _dev_f32(a, dev), _dev_f32(w, dev)
     b = _dev_f32(bias, dev) if bias is not None else None
-    _check(lib().tamf_test_gemm(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
+    _check(hooks().tamf_test_gemm(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
                                 c_void_p(b.data_ptr() if b is not None else 0), act, c_void_p(c.data_ptr()),
-                                c_void_p(_stream_ptr(dev))))
+                                c_void_p(_stream_ptr(dev))), None, hooks())
     return c
 
 
@@ -425,10 +453,10 @@ def test_gemm_resid(precision: str, a, w, bb, gamma, x, stats_in=None):
     y = _dev_f32(x, dev).clone()
     st_in = _dev_f32(stats_in, dev) if stats_in is not None else None
     st_out = torch.empty((M, N // 32, 2), device=dev, dtype=torch.float32)
-    _check(lib().tamf_test_gemm_resid(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
+    _check(hooks().tamf_test_gemm_resid(PRECISIONS[precision], M, N, K, c_void_p(a.data_ptr()), c_void_p(w.data_ptr()),
                                       c_void_p(bb.data_ptr()), c_void_p(gamma.data_ptr()),
                                       c_void_p(st_in.data_ptr() if st_in is not None else 0), c_void_p(y.data_ptr()),
-                                      c_void_p(st_out.data_ptr()), c_void_p(_stream_ptr(dev))))
+                                      c_void_p(st_out.data_ptr()), c_void_p(_stream_ptr(dev))), None, hooks())
     return y, st_out
 
 
@@ -438,15 +466,15 @@ def test_attention(precision: str, qkv: torch.Tensor, H: int) -> torch.Tensor:
     d = D3 // 3
     out = torch.empty((B, S, d), device=dev, dtype=torch.float32)
     q = _dev_f32(qkv, dev)
-    _check(lib().tamf_test_attention(PRECISIONS[precision], B, S, H, d // H, c_void_p(q.data_ptr()), c_void_p(out.data_ptr()),
-                                     c_void_p(_stream_ptr(dev))))
+    _check(hooks().tamf_test_attention(PRECISIONS[precision], B, S, H, d // H, c_void_p(q.data_ptr()), c_void_p(out.data_ptr()),
+                                     c_void_p(_stream_ptr(dev))), None, hooks())
     return out
 
 
 def test_philox(seed: int, clip_id_base: int, draw: int, B: int, F: int, T: int, device=None) -> torch.Tensor:
     dev = require_gpu(device)
     out = torch.empty((B, F, 1, T), device=dev, dtype=torch.float32)
-    _check(lib().tamf_test_philox(seed, clip_id_base, draw, B, F, T, c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))))
+    _check(hooks().tamf_test_philox(seed, clip_id_base, draw, B, F, T, c_void_p(out.data_ptr()), c_void_p(_stream_ptr(dev))), None, hooks())
     torch.cuda.synchronize(dev)
     return out
 
@@ -457,5 +485,5 @@ def mfma_sustained_rate(precision: str, millis: int = 1500, device=None) -> Tupl
     dev = require_gpu(device)
     tf, mhz = ctypes.c_float(), ctypes.c_float()
     with torch.cuda.device(dev):
-        _check(lib().tamf_bench_mfma_rate(PRECISIONS[precision], int(millis), ctypes.byref(tf), ctypes.byref(mhz), c_void_p(_stream_ptr(dev))))
+        _check(hooks().tamf_bench_mfma_rate(PRECISIONS[precision], int(millis), ctypes.byref(tf), ctypes.byref(mhz), c_void_p(_stream_ptr(dev))), None, hooks())
     return float(tf.value), float(mhz.value)

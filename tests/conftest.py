@@ -69,6 +69,20 @@ def load_trained_sd(name):
     return sd, meta
 
 
+@pytest.fixture
+def test_hooks():
+    """GPU tests that need include/tamf_hip_test.h (kernel-selection overrides, guard bands, failure injection): for the duration of the
+    test, contexts are created through libtamf_hip_hooks.so - the -DTAMF_TEST_HOOKS build of the same sources - and
+    hip_backend.lib() is that library.  Every other GPU test runs on libtamf_hip.so, which exports the drop-in surface only."""
+    from oakink2_tamf_amd import hip_backend as hb
+
+    hb.use_test_hooks(True)
+    try:
+        yield hb.hooks()
+    finally:
+        hb.use_test_hooks(False)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

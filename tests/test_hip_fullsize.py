@@ -269,7 +269,7 @@ def test_forward_clip_tiles_at_their_largest_padding(prec, B, T):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
 @pytest.mark.parametrize("B,arch_name", [(64, "ARCH_MDM_L"), (32, "ARCH_MDM_L"), (64, "ARCH_MDM")])
-def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name):
+def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name, test_hooks):
     """27 clip lengths between T = 139 and 204 (every fourth one plus the edges of the tile families; Sp = 144 .. 216: below, inside and
     above the 176- / 208-row clip tiles and their row parts): the default kernels against the 128 x 128 tiles (selection 1: no clip
     tiles at all) - the same bits - and finite.  (T = 172 .. 187 and 140 .. 155 used to run the f32 V^T clip tile past the V^T rows:
@@ -304,7 +304,7 @@ def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
 @pytest.mark.parametrize("T", [196, 160])
-def test_kernel_choice_over_batch_sizes(prec, T):
+def test_kernel_choice_over_batch_sizes(prec, T, test_hooks):
     """The launch rules switch kernels with the batch size (clip tiles from 74 % fill, row-part tiles up to half the CUs, query splits of the
     attention, 64-row tiles for short-K GEMMs, row-part tiles of the residual GEMMs at 32 clips or fewer): at 24 batch sizes from 1 to 128 the default
     kernels against selection 1 (no clip tiles anywhere) - the same bits - and clip 0 of every batch against clip 0 alone."""
@@ -340,7 +340,7 @@ def test_kernel_choice_over_batch_sizes(prec, T):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
-def test_refine_and_loop_over_clip_lengths(prec):
+def test_refine_and_loop_over_clip_lengths(prec, test_hooks):
     """The R trunk (3 prefix tokens: S = T + 3) and the hipGraph sampling loop of G (20 steps, device Philox) over clip lengths around
     the clip tiles' limits, B = 64: default kernels against selection 1 (no clip tiles) - the same bits, finite."""
     from oracle import mdm_oracle as O
@@ -388,7 +388,7 @@ def test_refine_and_loop_over_clip_lengths(prec):
     assert not bad, (prec, bad)
 
 
-def test_modes_agree_on_random_shapes():
+def test_modes_agree_on_random_shapes(test_hooks):
     """48 random (B, T) shapes, B in [1, 130], T in [8, 204] - most of them shapes no other test visits: the four arithmetic modes run
     different kernels for the same launch (f32: clip tiles for QKV and out-proj, its own LayerNorm forms; bf16: LayerNorm fused into
     FFN2; the split modes: neither), so a slip in one mode's path shows as a disagreement far above the modes' rounding differences."""
@@ -433,7 +433,7 @@ SELECTIONS = {
 
 
 @pytest.mark.parametrize("prec", PRECS)
-def test_kernel_selections_give_the_same_bits(full, prec):
+def test_kernel_selections_give_the_same_bits(full, prec, test_hooks):
     from oakink2_tamf_amd.hip_backend import lib
 
     B = 48  # (1.5 rounds of clip tiles for FFN2: remainders too)
@@ -451,7 +451,7 @@ def test_kernel_selections_give_the_same_bits(full, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-def test_small_and_mid_batch_tiles_give_the_same_bits(full, full160, prec):
+def test_small_and_mid_batch_tiles_give_the_same_bits(full, full160, prec, test_hooks):
     """Calls of a few clips run their GEMMs on gemm_deep_kernel (csrc/tamf_gemm_deep.h: 32 x 64 / 32 x 128 / 64 x 128 tiles with a 3- to
     6-stage K pipeline; one clip per call is the reference launcher's own pattern, launch/sample.py:202-229), 20 - 39 clips of the 16-bit
     modes their residual GEMMs: same bits as the tiles of the big batches (selection bit 16), and within the tolerance of the oracle."""
@@ -559,7 +559,7 @@ def test_forward_other_batch_sizes_t160(full160, prec, B):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-def test_kernel_selections_give_the_same_bits_t160(full160, prec):
+def test_kernel_selections_give_the_same_bits_t160(full160, prec, test_hooks):
     from oakink2_tamf_amd.hip_backend import lib
 
     B = 48

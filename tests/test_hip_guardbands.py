@@ -22,11 +22,15 @@ LENGTHS = range(1, 225)
 
 @pytest.fixture(scope="module", autouse=True)
 def guard_mode():
-    from oakink2_tamf_amd.hip_backend import set_guard_bytes
+    """the guard bands, tamf_test_poke and the allocation-failure injection live in libtamf_hip_hooks.so (include/tamf_hip_test.h): the
+    contexts of this module are created through it"""
+    from oakink2_tamf_amd.hip_backend import set_guard_bytes, use_test_hooks
 
+    use_test_hooks(True)
     set_guard_bytes(GUARD)
     yield
     set_guard_bytes(0)
+    use_test_hooks(False)
 
 
 def _inputs(B, T, nobj=2):

@@ -138,11 +138,11 @@ def test_attention_streaming_kernel(hb, prec, B, S, H, hd, tuning):
     k = k.view(B, S, H, hd).transpose(1, 2)
     v = v.view(B, S, H, hd).transpose(1, 2)
     ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1) @ v).transpose(1, 2).reshape(B, S, d)
-    hb.lib().tamf_set_gemm_tuning(tuning)
+    hb.hooks().tamf_set_gemm_tuning(tuning)
     try:
         got = hb.test_attention(prec, qkv.cuda(), H)
     finally:
-        hb.lib().tamf_set_gemm_tuning(-1)
+        hb.hooks().tamf_set_gemm_tuning(-1)
     assert torch.isfinite(got).all()
     assert _rel(got, ref) < {"f32": 2e-5, "f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
 
@@ -158,11 +158,11 @@ def test_attention_online_softmax_rescale(hb, tuning):
     q, k, v = qkv.double().split(hd, dim=-1)
     att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
     ref = att @ v
-    hb.lib().tamf_set_gemm_tuning(tuning)
+    hb.hooks().tamf_set_gemm_tuning(tuning)
     try:
         got = hb.test_attention("f32", qkv.cuda(), H)
     finally:
-        hb.lib().tamf_set_gemm_tuning(-1)
+        hb.hooks().tamf_set_gemm_tuning(-1)
     assert _rel(got, ref) < 2e-5
 
 

@@ -13,4 +13,9 @@ _path = os.environ.get("TAMF_LIB_OVERRIDE")
 if _path:
     from oakink2_tamf_amd import _lib
 
-    _lib.load_from(_path)
+    _lib.load_from(_path)  # (stands for the product AND the hooks library: tools/ab_build.sh compiles with -DTAMF_TEST_HOOKS)
+
+# measurement tools work on libtamf_hip_hooks.so (tamf_set_gemm_tuning, tamf_bench_*, tamf_debug_timeline live there only)
+from oakink2_tamf_amd import hip_backend as _hb  # noqa: E402
+
+_hb.use_test_hooks(True)

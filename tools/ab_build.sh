@@ -9,11 +9,11 @@ name=${2:-A}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out="$root/oakink2-tamf_amd/oakink2_tamf_amd/lib/libtamf_hip_$name.so"
 if [ "$ref" = WORKTREE ]; then
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -o "$out" "$root/oakink2-tamf_amd/csrc/tamf_hip.hip" $TAMF_HIPCC_FLAGS
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-unused-function -DTAMF_TEST_HOOKS -o "$out" "$root/oakink2-tamf_amd/csrc/tamf_hip.hip" $TAMF_HIPCC_FLAGS
 else
   tmp=$(mktemp -d)
   git -C "$root" archive "$ref" oakink2-tamf_amd/csrc include | tar -x -C "$tmp"
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -o "$out" "$tmp/oakink2-tamf_amd/csrc/tamf_hip.hip" $TAMF_HIPCC_FLAGS
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-unused-function -DTAMF_TEST_HOOKS -o "$out" "$tmp/oakink2-tamf_amd/csrc/tamf_hip.hip" $TAMF_HIPCC_FLAGS
   rm -rf "$tmp"
 fi
 echo "built $(basename "$out") from $ref ${TAMF_HIPCC_FLAGS}"
