@@ -43,6 +43,17 @@ TAMF_DEV void gst8(void* p, uint32_t a, uint32_t b) {
   const tamf_u32x2 v = {a, b};
   *(tamf_u32x2*)p = v;
 }
+#ifdef TAMF_H_NT  // (A/B build, round 6: the FFN hidden activations - 109 MB per launch in the split modes, read once by FFN2 - stored
+// non-temporally, so that they do not push the weight panel and the clips' A panels out of the XCD's L2: DESIGN.md section 6, "re-fetch")
+TAMF_DEV void gst16_nt(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  const tamf_u32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, (tamf_u32x4*)p);
+}
+TAMF_DEV void gst8_nt(void* p, uint32_t a, uint32_t b) {
+  const tamf_u32x2 v = {a, b};
+  __builtin_nontemporal_store(v, (tamf_u32x2*)p);
+}
+#endif
 TAMF_DEV void gst16f(float* p, float a, float b, float c, float d) {
   gst16(p, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
 }
@@ -194,7 +205,7 @@ struct OpF32 {
   static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) { mma(acc, x, w); }
   // byte offset of logical element idx (row * ld + col; ld % 32 == 0) from the matrix base
   static TAMF_DEV long byte_off(long idx) { return idx * 4; }
-  template <int N>
+  template <int N, bool NT = false>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     float* p = base + idx;
     if constexpr (N == 8) {
@@ -206,15 +217,19 @@ struct OpF32 {
       *(float2*)p = make_float2(v[0], v[1]);
     }
   }
-  template <int N>
-  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  template <int N, bool NT = false>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N, NT>(base, idx, v); }  // (fp32 exponent range: nothing to check)
   static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = v; }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return base[idx]; }
 };
 
-template <int N>
+template <int N, bool NT = false>
 TAMF_DEV void store_bf16_vec(char* p, const uint32_t* w) {
+#ifdef TAMF_H_NT
+  if constexpr (NT && N == 8) { gst16_nt(p, w[0], w[1], w[2], w[3]); return; }
+  if constexpr (NT && N == 4) { gst8_nt(p, w[0], w[1]); return; }
+#endif
   if constexpr (N == 8) {
     gst16(p, w[0], w[1], w[2], w[3]);
   } else if constexpr (N == 4) {
@@ -239,15 +254,15 @@ struct OpBF16 {
   }
   static TAMF_DEV void mma_t(f32x4& acc, const int4 (&x)[2], const int4 (&w)[2]) { mma(acc, x, w); }
   static TAMF_DEV long byte_off(long idx) { return idx * 2; }
-  template <int N>
+  template <int N, bool NT = false>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t w[N / 2];
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) w[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
-    store_bf16_vec<N>((char*)base + idx * 2, w);
+    store_bf16_vec<N, NT>((char*)base + idx * 2, w);
   }
-  template <int N>
-  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  template <int N, bool NT = false>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N, NT>(base, idx, v); }  // (fp32 exponent range: nothing to check)
   static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) { base[idx] = (uint16_t)f2bf(v); }
   static TAMF_DEV float load1(const elem_t* base, long idx) { return bf2f(base[idx]); }
@@ -276,17 +291,17 @@ struct OpBF16X3 {
   }
   // element idx lives in 128-byte group idx / 32: hi at 2 * (idx % 32), lo 64 bytes further
   static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
-  template <int N>
+  template <int N, bool NT = false>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t wh[N / 2], wl[N / 2];
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) split_bf16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
     char* p = (char*)base + byte_off(idx);
-    store_bf16_vec<N>(p, wh);
-    store_bf16_vec<N>(p + 64, wl);
+    store_bf16_vec<N, NT>(p, wh);
+    store_bf16_vec<N, NT>(p + 64, wl);
   }
-  template <int N>
-  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N>(base, idx, v); }  // (fp32 exponent range: nothing to check)
+  template <int N, bool NT = false>
+  static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float&) { store<N, NT>(base, idx, v); }  // (fp32 exponent range: nothing to check)
   static TAMF_DEV void range_flag(float, unsigned*) {}
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {
 #pragma clang fp contract(off)
@@ -326,23 +341,23 @@ struct OpF16X3 {
     acc = mfma1(x[0], w[0], acc);
   }
   static TAMF_DEV long byte_off(long idx) { return ((idx >> 5) << 7) + ((idx & 31) << 1); }
-  template <int N>
+  template <int N, bool NT = false>
   static TAMF_DEV void store(elem_t* base, long idx, const float* v) {
     uint32_t wh[N / 2], wl[N / 2];
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) split_f16x3(v[2 * i], v[2 * i + 1], wh[i], wl[i]);
     char* p = (char*)base + byte_off(idx);
-    store_bf16_vec<N>(p, wh);
-    store_bf16_vec<N>(p + 64, wl);
+    store_bf16_vec<N, NT>(p, wh);
+    store_bf16_vec<N, NT>(p + 64, wl);
   }
   // range-checked store: folds max |v| of the run into the caller's accumulator `am` (v_max3_f32 with |.| modifiers: one
   // instruction per pair, NaN operands drop out); the caller raises the status bit ONCE, after its loops (range_flag) - a
   // compare + branch + atomic inside a row loop keeps the compiler from pipelining it (QKV epilogue: 66 -> 82 us)
-  template <int N>
+  template <int N, bool NT = false>
   static TAMF_DEV void store_rc(elem_t* base, long idx, const float* v, float& am) {
 #pragma unroll
     for (int i = 0; i < N / 2; ++i) am = fmaxf(fmaxf(am, fabsf(v[2 * i])), fabsf(v[2 * i + 1]));
-    store<N>(base, idx, v);
+    store<N, NT>(base, idx, v);
   }
   static TAMF_DEV void range_flag(float am, unsigned* status) { f16_range_flag(am, status); }
   static TAMF_DEV void store1(elem_t* base, long idx, float v) {

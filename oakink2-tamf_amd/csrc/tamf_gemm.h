@@ -238,6 +238,9 @@ struct EpiBiasAct {
         for (int j = 0; j < N; ++j) v[j] = gelu_erf_fast(v[j]);
       }
     }
+#ifdef TAMF_H_NT
+    if (a == ACT_GELU) { OutOp::template store_rc<N, true>(out, (long)gr * ldo + gn, v, am); return; }  // (the FFN hidden activations: A/B build)
+#endif
     OutOp::template store_rc<N>(out, (long)gr * ldo + gn, v, am);
   }
   // register form: a lane stores 16 bytes per instruction - 4 columns of a 4-byte output, 8 of a 16-bit plane

@@ -29,6 +29,20 @@ def _sub(cond, sl):
     return {k: (v[sl] if isinstance(v, torch.Tensor) else list(v[sl])) for k, v in cond.items()}
 
 
+def _oracle_loop5(fx, tag, T):
+    """(draws, oracle.sample_loop result) of the 5-step supplied-noise loop at B = 64: computed on first use, kept in the module fixture"""
+    if "loop5" not in fx:
+        from oracle import det
+        from oracle import mdm_oracle as O
+
+        shape = (B_FULL, 99, 1, T)
+        draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(tag, k), shape) for k in range(6)]))
+        with torch.no_grad():
+            ref = O.sample_loop(fx["sd"], fx["arch"], O.make_tables(5, "cosine"), fx["cond"], shape, lambda k: draws[k])
+        fx["loop5"] = (draws, ref)
+    return fx["loop5"]
+
+
 @pytest.fixture(scope="module")
 def full():
     """weights, conditioning, input and the oracle's outputs for the bench shape (computed once: ~5 s per forward)"""
@@ -78,11 +92,7 @@ def test_loop5_b64_t196_vs_oracle(full, prec):
     from oracle import mdm_oracle as O
 
     N = 5
-    tab = O.make_tables(N, "cosine")
-    shape = (B_FULL, 99, 1, T_FULL)
-    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag("full/eps", k), shape) for k in range(N + 1)]))
-    with torch.no_grad():
-        ref = O.sample_loop(full["sd"], full["arch"], tab, full["cond"], shape, lambda k: draws[k])
+    draws, ref = _oracle_loop5(full, "full/eps", T_FULL)  # (the oracle's 5 steps at B = 64 take 20 s on the host: once per module, not per mode)
     ctx = _make_ctx(full["arch"], full["sd"], B_FULL, T_FULL, prec, n_steps=N)
     _set_cond(ctx, full["cond"])
     out = ctx.sample_loop(noise=draws).cpu()
@@ -281,24 +291,27 @@ def test_clip_tiles_over_the_clip_lengths_they_accept(prec, B, arch_name, test_h
     arch = getattr(O, arch_name)  # (ARCH_MDM: the reference's smaller denoiser - other GEMM widths, 64-wide heads)
     sd = O.det_state_dict(arch, tag="full/w")
     bad = []
+    lengths = list(range(139, 205, 4)) + [147, 155, 156, 171, 172, 179, 187, 188, 203, 204]
+    # ONE context for all lengths (the kernels are chosen by the shape of the call, not by the context's capacity; a context per length
+    # spent most of this test uploading and repacking 109 MB of weights 27 times)
+    ctx = _make_ctx(arch, sd, B, max(lengths), prec)
     try:
-        for T in list(range(139, 205, 4)) + [147, 155, 156, 171, 172, 179, 187, 188, 203, 204]:
+        for T in lengths:
             cond = O.det_cond(B, T, tag="sweep/c", arch=arch)
             g = torch.Generator().manual_seed(T)
             x = torch.randn(B, 99, 1, T, generator=g)
             t = torch.randint(0, 1000, (B,), generator=g)
-            ctx = _make_ctx(arch, sd, B, T, prec)
             _set_cond(ctx, cond)
             lib().tamf_set_gemm_tuning(-1)
             a = ctx.denoise(x, t).cpu()
             lib().tamf_set_gemm_tuning((1 << 20) | 0xFFFFF)
             b = ctx.denoise(x, t).cpu()
             lib().tamf_set_gemm_tuning(-1)
-            ctx.close()
             if not (torch.isfinite(a).all() and torch.equal(a, b)):
                 bad.append((T, float((a - b).abs().max())))
     finally:
         lib().tamf_set_gemm_tuning(-1)
+        ctx.close()
     assert not bad, (prec, B, bad)
 
 
@@ -320,22 +333,22 @@ def test_kernel_choice_over_batch_sizes(prec, T, test_hooks):
     t = torch.randint(0, 1000, (BMAX,), generator=g)
     bad = []
     alone = None
+    ctx = _make_ctx(arch, sd, BMAX, T, prec)  # (one context: see test_clip_tiles_over_the_clip_lengths_they_accept)
     try:
         for B in [1, 2, 3, 5, 8, 13, 16, 21, 24, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 72, 96, 127, 128]:
-            ctx = _make_ctx(arch, sd, B, T, prec)
             _set_cond(ctx, _sub(cond, slice(0, B)))
             lib().tamf_set_gemm_tuning(-1)
             a = ctx.denoise(x[:B], t[:B]).cpu()
             lib().tamf_set_gemm_tuning((1 << 20) | 0xFFFFF)
             b = ctx.denoise(x[:B], t[:B]).cpu()
             lib().tamf_set_gemm_tuning(-1)
-            ctx.close()
             if alone is None:
                 alone = a[0].clone()
             if not (torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[0], alone)):
                 bad.append((B, float((a - b).abs().max()), float((a[0] - alone).abs().max())))
     finally:
         lib().tamf_set_gemm_tuning(-1)
+        ctx.close()
     assert not bad, (prec, T, bad)
 
 
@@ -352,9 +365,9 @@ def test_refine_and_loop_over_clip_lengths(prec, test_hooks):
         sd = O.det_state_dict(arch, tag="fullr/w")
         for T in [141, 150, 158, 160, 173, 174, 176, 181, 189, 190, 196, 205]:
             cond = O.det_cond(64, T, tag="rsweep/c", arch=arch)
-            g = torch.Generator().manual_seed(T)
-            x_in = torch.randn(64, T, 99, generator=g)
-            h2o = torch.rand(64, T, 778, generator=g) * 0.2
+            g = torch.Generator(device="cuda").manual_seed(T)  # (10 M normals per length: drawn on the device)
+            x_in = torch.randn(64, T, 99, generator=g, device="cuda")
+            h2o = torch.rand(64, T, 778, generator=g, device="cuda") * 0.2
             ctx = _make_ctx(arch, sd, 64, T, prec)
             _set_cond(ctx, cond)
             lib().tamf_set_gemm_tuning(-1)
@@ -388,7 +401,7 @@ def test_refine_and_loop_over_clip_lengths(prec, test_hooks):
     assert not bad, (prec, bad)
 
 
-def test_modes_agree_on_random_shapes(test_hooks):
+def test_modes_agree_on_random_shapes():
     """48 random (B, T) shapes, B in [1, 130], T in [8, 204] - most of them shapes no other test visits: the four arithmetic modes run
     different kernels for the same launch (f32: clip tiles for QKV and out-proj, its own LayerNorm forms; bf16: LayerNorm fused into
     FFN2; the split modes: neither), so a slip in one mode's path shows as a disagreement far above the modes' rounding differences."""
@@ -400,23 +413,25 @@ def test_modes_agree_on_random_shapes(test_hooks):
     shapes = [(int(rng.randint(1, 131)), int(rng.randint(8, 205))) for _ in range(48)]
     tol = {"f16x3": 3e-5, "bf16x3": 2e-4, "bf16": 6e-2}
     bad = []
+    # one context per mode for all 48 shapes (192 contexts = 192 weight uploads before)
+    ctxs = {prec: _make_ctx(arch, sd, max(b for b, _ in shapes), max(t_ for _, t_ in shapes), prec) for prec in ["f32", "f16x3", "bf16x3", "bf16"]}
     for B, T in shapes:
         cond = O.det_cond(B, T, tag="rand/c", arch=arch)
         g = torch.Generator().manual_seed(B * 1000 + T)
         x = torch.randn(B, 99, 1, T, generator=g)
         t = torch.randint(0, 1000, (B,), generator=g)
         outs = {}
-        for prec in ["f32", "f16x3", "bf16x3", "bf16"]:
-            ctx = _make_ctx(arch, sd, B, T, prec)
+        for prec, ctx in ctxs.items():
             _set_cond(ctx, cond)
             outs[prec] = ctx.denoise(x, t).cpu()
-            ctx.close()
         for prec, tl in tol.items():
             d = float((outs[prec] - outs["f32"]).abs().max())
             if not (torch.isfinite(outs[prec]).all() and d < tl):
                 bad.append((B, T, prec, d))
         if not torch.isfinite(outs["f32"]).all():
             bad.append((B, T, "f32", float("nan")))
+    for ctx in ctxs.values():
+        ctx.close()
     assert not bad, bad
 
 
@@ -514,11 +529,7 @@ def test_loop5_b64_t160_vs_oracle(full160, prec):
     from oracle import mdm_oracle as O
 
     N = 5
-    tab = O.make_tables(N, "cosine")
-    shape = (B_FULL, 99, 1, T_DS)
-    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag("full160/eps", k), shape) for k in range(N + 1)]))
-    with torch.no_grad():
-        ref = O.sample_loop(full160["sd"], full160["arch"], tab, full160["cond"], shape, lambda k: draws[k])
+    draws, ref = _oracle_loop5(full160, "full160/eps", T_DS)
     ctx = _make_ctx(full160["arch"], full160["sd"], B_FULL, T_DS, prec, n_steps=N)
     _set_cond(ctx, full160["cond"])
     out = ctx.sample_loop(noise=draws).cpu()

@@ -88,13 +88,18 @@ def test_r_every_clip_length_writes_inside_its_buffers(prec):
     ctx = TamfContext(a, 1, 1, precision=prec, device="cuda:0", kind="R")
     ctx.load_state_dict(sd)
     bad = []
+    g = torch.Generator().manual_seed(5)
+    nmax = max(BATCHES) * max(LENGTHS)
+    pool_x = torch.randn(nmax * 99 + 1000, generator=g).cuda()
+    pool_h = (torch.randn(nmax * 778 + 1000, generator=g) * 0.05).cuda()
     for B in BATCHES:
         for T in LENGTHS:
             ctx.resize(B, T)
             i = _inputs(B, T, nobj=3)
             ctx.set_cond(None, i["side"], i["shape"], i["emb"], i["traj"])
-            g = torch.Generator().manual_seed(T)
-            out = ctx.refine(torch.randn(B, T, 99, generator=g).cuda(), (torch.randn(B, T, 778, generator=g) * 0.05).cuda())
+            # (inputs: windows of two device tensors drawn once - 11 M CPU normals per shape were 3/4 of this test's 47 s)
+            o = ((B * 131 + T * 17) % 15) * 64  # (256-byte aligned windows)
+            out = ctx.refine(pool_x[o:o + B * T * 99].view(B, T, 99), pool_h[o:o + B * T * 778].view(B, T, 778))
             try:
                 ctx.check_guards()
             except TamfError as e:
