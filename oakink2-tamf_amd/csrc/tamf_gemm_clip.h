@@ -79,6 +79,11 @@ struct ClipGemmArgs {
   // skipped on the store side like a clip's own padding).  Used when whole-clip tiles would fill at most half of the CUs
   // (32 clips per GPU): same products in the same K order per output element, i.e. the same bits as the whole-clip tiles.
   int split_rows;
+  // > 0 (= N / BN, the column tiles of a clip): COLUMN-SPLIT ROUNDS - the launch is R = n_tiles / grid exact rounds and round r takes
+  // column tiles [r ntn / R, (r + 1) ntn / R) of EVERY clip, instead of all column tiles of the r-th R-th of the clips.  An XCD's chunk of
+  // a round is then (R x as many clips) x (ntn / R column tiles): the weight rows it streams per round shrink by R and can stay in its
+  // 4-MB L2 (FFN1, split modes: 2 MB instead of the whole 4-MB matrix), the A panels it fetches double.  Same tiles, same bits.
+  int colsplit;
   int abl;          // kernel-benchmark ablations (-DTAMF_BENCH builds only, TAMF_ABL) (tools/kbench.py): 1 = no loads after the first K tiles, 2 = no MFMAs, 4 = no epilogue,
                     // 8 = no activation, 16 = every row tile is stored into the rows of the first one (no new lines to write back)
 };
@@ -338,11 +343,19 @@ TAMF_DEV void clip_mma_y(const int4 (&wf)[NI][2], const int4 (&af)[C::MSUBY][2],
 
 // tile of this workgroup in round `r` of the persistent grid (-1: none): inside a round the XCDs own contiguous chunks of
 // the tile list (xcd_remap), i.e. a few whole clips x all their column tiles - a clip's A panel is fetched into one L2
-TAMF_DEV int clip_tile_of(int n_tiles, int round) {
+template <class Op>
+TAMF_DEV int clip_tile_of(const ClipGemmArgs<Op>& ga, int round) {
+  const int n_tiles = ga.n_tiles;
   const int G = gridDim.x, base = round * G;
   if (base >= n_tiles) return -1;
   const int cnt = n_tiles - base < G ? n_tiles - base : G;
-  return (int)blockIdx.x < cnt ? base + xcd_remap(blockIdx.x, cnt) : -1;
+  if ((int)blockIdx.x >= cnt) return -1;
+  const int i = xcd_remap(blockIdx.x, cnt);
+  if (ga.colsplit > 0) {  // (n_tiles = R G exactly, ntn = R per: ClipLaunch::launch)
+    const int per = ga.colsplit / (n_tiles / G);
+    return (i / per) * ga.colsplit + round * per + i % per;
+  }
+  return base + i;
 }
 
 // Register epilogue of one wave: row tile mi of the wave -> row row0 + 16 mi of the clip; chunk c of the lane = columns
@@ -548,7 +561,7 @@ struct ClipStream {
     load_src(ga, ntn, nq, prow, pch);
   }
   TAMF_DEV void load_src(const ClipGemmArgs<Op>& ga, int ntn, int nq, int prow, int pch) {
-    const int t = clip_tile_of(ga.n_tiles, ri);
+    const int t = clip_tile_of(ga, ri);
     live = t >= 0;
     if (live) s = clip_src<Op, C>(ga, t / ntn, (t % ntn) * C::BN, nq, prow, pch);
   }
@@ -568,7 +581,7 @@ template <class Op, class C, class Epi>
 TAMF_DEV void clip_stage_first(const ClipGemmArgs<Op>& ga, const Epi& epi, int ntn, float2* rstat, int tid) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const int tr = clip_tile_of(ga.n_tiles, r);
+    const int tr = clip_tile_of(ga, r);
     if (tr >= 0) {
       int base, rows;
       clip_part(ga, tr / ntn, base, rows);
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     }
     clip_barrier_lds();
     int round = 0, kt = 0, sc = 0, sn = LA % NS;
-    int t = clip_tile_of(ga.n_tiles, 0);
+    int t = clip_tile_of(ga, 0);
     bool pre = false;  // this interval's requests went out ahead of the previous tile's epilogue
     for (int j = 0; j < J; ++j) {
       const bool ld = is.live && !(TAMF_ABL(ga.abl) & 1) && !pre, batch = ld || pre;
@@ -715,13 +728,13 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         kt = 0;
-        t = clip_tile_of(ga.n_tiles, ++round);
+        t = clip_tile_of(ga, ++round);
         if constexpr (Epi::ROWSTATS) {
           // tiles 0 and 1 were staged up front; entering tile `round` >= 1, tile round + 1 (if any) goes into slot (round + 1) % 3 = the
           // slot of tile round - 2, which nobody reads any more (Y stored tile round - 2 before a barrier X passed a whole tile ago;
           // Y may still be storing tile round - 1 from ITS slot)
           if (round >= 1) {
-            const int tn = clip_tile_of(ga.n_tiles, round + 1);
+            const int tn = clip_tile_of(ga, round + 1);
             if (tn >= 0) {
               int base, rows;
               clip_part(ga, tn / ntn, base, rows);
@@ -748,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
     clip_read_y<C, NI>(smem, a_frag, w_frag, c0, c1, ywf, yaf);
     clip_barrier_lds();  // (the fragment reads are complete: lgkmcnt(0) before every barrier)
     int round = 0, kt = 0, sc = 1 % NS;
-    int t = clip_tile_of(ga.n_tiles, 0);
+    int t = clip_tile_of(ga, 0);
     for (int j = 1; j <= J; ++j) {
 #ifdef TAMF_TIMELINE
       const bool dbg_on = wave == 4 && j >= 4 && j < 12 && blockIdx.x < 512;
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void clip_gemm_kernel(const ClipGemmArgs<Op
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         kt = 0;
-        t = clip_tile_of(ga.n_tiles, ++round);
+        t = clip_tile_of(ga, ++round);
       }
       if (j == J) break;
       if constexpr (!YFUSE) clip_read_y<C, NI>(smem + sc * C::STAGE, a_frag, w_frag, c0, c1, ywf, yaf);

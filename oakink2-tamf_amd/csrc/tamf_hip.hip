@@ -309,6 +309,7 @@ static int g_krot = -1;
 // kernel-selection overrides for A/B measurements (tamf_set_gemm_tuning bits 20..): 1 = no clip tiles at all,
 // 2 = FFN2 / out-proj on the 128 x 128 tiles, 4 = attention split once more, 8 = FFN1 on the 128 x 128 tiles,
 // 16 = residual GEMMs of a few clips on the clip / 128 x 128 tiles too (no 32- / 64-row tiles), 64 = f32: QKV on the 128 x 128 tiles,
+// 32 = FFN1 (whole-clip tiles in two or more exact rounds): column-split rounds toggled against TAMF_CLIP_COLSPLIT_DEFAULT,
 // 256 = (-DTAMF_OVERLAP_PROBE / -DTAMF_BENCH builds only) OVERLAP PROBE: the launches of a no-graph loop alternate between two streams with no data
 //       dependency enforced - garbage samples, the time is an upper bound of what removing the kernel boundaries could gain (PingPong),
 // 512 = streaming attention kernel in the 16-bit modes too,
@@ -317,6 +318,9 @@ static int g_krot = -1;
 // of the residual GEMMs - gone with the deferred LayerNorm, which every mode uses now; 32 / 128: clip-tile variants of FFN1 / QKV that
 // lost their A/B.  The bits are accepted and ignored.)
 static int g_sel = 0;
+#ifndef TAMF_CLIP_COLSPLIT_DEFAULT  // FFN1's rounds split by columns (selection bit 32 toggles it against this default: A/B)
+#define TAMF_CLIP_COLSPLIT_DEFAULT 0
+#endif
 static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_tile ? (4 << 8) : 0); }
 
 // resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch.  Per DEVICE (one
@@ -510,9 +514,14 @@ struct ClipLaunch {
     if (e != hipSuccess) return e;
     static_assert(PARTS == 1 || PARTS == 2, "whole clips or their two row parts");
     constexpr int split_rows = PARTS == 1 ? 0 : NSUB * 16;
-    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, PARTS * n_clips * (N / C::BN), split_rows,
+    ClipGemmArgs<Op> ga{A, lda, W, ldw, n_clips, Sp, N, K, PARTS * n_clips * (N / C::BN), split_rows, 0,
                         g_krot >= 0 ? ((g_krot >> 12) & 15) | (((g_krot >> 17) & 3) << 4) : 0};
     const int cus = wg_slots() / 2;
+    {  // column-split rounds (tamf_gemm_clip.h, ClipGemmArgs::colsplit): whole clips, two or more EXACT rounds, column tiles divisible
+      const int ntn = N / C::BN, rounds = ga.n_tiles / cus;
+      const bool fits = PARTS == 1 && ga.n_tiles > cus && ga.n_tiles % cus == 0 && ntn % rounds == 0 && NI == 4;
+      if (fits && (TAMF_CLIP_COLSPLIT_DEFAULT != 0) != ((g_sel & 32) != 0)) ga.colsplit = ntn;
+    }
     hipLaunchKernelGGL((clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>), dim3(ga.n_tiles < cus ? ga.n_tiles : cus), dim3(512), C::BYTES, st, ga, epi);
     return hipGetLastError();
   }

@@ -466,6 +466,25 @@ def test_kernel_selections_give_the_same_bits(full, prec, test_hooks):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_ffn1_column_split_rounds_give_the_same_bits(full, prec, test_hooks):
+    """Selection bit 32 (round 6): FFN1's two rounds of whole-clip tiles at B = 64 split by COLUMNS (every clip's column tiles 0 - 3, then
+    4 - 7) instead of by clips - another order of the same tiles: the same bits, against the oracle too."""
+    from oakink2_tamf_amd.hip_backend import lib
+
+    ctx = _make_ctx(full["arch"], full["sd"], B_FULL, T_FULL, prec)
+    _set_cond(ctx, full["cond"])
+    try:
+        ref = ctx.denoise(full["x"], full["t"]).cpu()
+        lib().tamf_set_gemm_tuning((0x020 << 20) | 0xFFFFF)
+        got = ctx.denoise(full["x"], full["t"]).cpu()
+        assert torch.equal(got, ref), (prec, float((got - ref).abs().max()))
+        assert float((got - full["ref"]).abs().max()) < FWD_TOL[prec]
+    finally:
+        lib().tamf_set_gemm_tuning(-1)
+        ctx.close()
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_small_and_mid_batch_tiles_give_the_same_bits(full, full160, prec, test_hooks):
     """Calls of a few clips run their GEMMs on gemm_deep_kernel (csrc/tamf_gemm_deep.h: 32 x 64 / 32 x 128 / 64 x 128 tiles with a 3- to
     6-stage K pipeline; one clip per call is the reference launcher's own pattern, launch/sample.py:202-229), 20 - 39 clips of the 16-bit
