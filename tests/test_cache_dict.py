@@ -200,3 +200,14 @@ def test_sample_launcher_reads_the_cache_dict_with_sample_sh_arguments(dataset_f
     uniq = list(R.unique_clips(items))
     assert [i for i, _ in uniq] == [0, 1, 2, 4]  # segment 3 repeats segment 2's info
     assert [len(g) for g in R.batches(uniq, 3)] == [3, 1]
+    # sizing the context and splitting the workers does not materialise the items: the adaptor's arrays / the cache's length
+    class _NoItems(type(items)):
+        def __getitem__(self, i):
+            raise AssertionError("max_sample_frames must not build items")
+    probe = object.__new__(_NoItems)
+    probe.__dict__.update(items.__dict__)
+    assert R.max_sample_frames(probe) == 160
+    assert R.max_sample_frames([{"sample_pose_repr": np.zeros((7, 99))}, {"sample_pose_repr": np.zeros((12, 99))}]) == 12  # (--data.clips_pkl lists)
+    built = []
+    monkeypatch.setattr(S, "CacheDictClips", lambda cfg_: built.append(cfg_) or (_ for _ in ()).throw(AssertionError("count_clips built the clip source")))
+    assert S.count_clips(cfg, known) == 5 and not built
