@@ -118,6 +118,13 @@ int tamf_finalize_weights(tamf_ctx* ctx, int32_t max_timesteps, void* stream);
  * exactly where the reference casts them (gaussian_diffusion.py:1275). */
 int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* posterior_mean_coef1,
                       const double* posterior_mean_coef2, const double* posterior_log_variance_clipped);
+/* Respaced sampling (reference model/diffusion/respace.py:60-119: SpacedDiffusion keeps a subset of the base process' timesteps and its
+ * _WrappedModel evaluates the denoiser at timestep_map[t]).  Call after tamf_set_schedule with the SAME n_steps: step i of the loop
+ * (i = n_steps - 1 .. 0, coefficients i of the schedule) evaluates the denoiser at timestep map_host[i] of the base process - strictly
+ * increasing entries inside the timestep table (max_timesteps of tamf_finalize_weights).  The library gathers the rows of its
+ * timestep-embedding table once; the captured loop is step-agnostic as before.  NULL restores the identity map, and so does every
+ * later tamf_set_schedule.  tamf_denoise is not affected (the caller's timesteps index the table directly, as _WrappedModel's do). */
+int tamf_set_timestep_map(tamf_ctx* ctx, int32_t n_steps, const int32_t* map_host);
 
 /* Conditioning of one batch (the `batch` dict of model.forward, CLIP output supplied as text_embedding):
  *   text_emb_dev  (B, clip_dim) f32 [G only, NULL for R]      hand_side_host (B,) uint8: 0 = "rh", 1 = "lh"

@@ -107,6 +107,12 @@ struct tamf_ctx {
   float *bm2 = nullptr, *bf = nullptr;
   float* pe = nullptr;    // [5000][d]
   float* temb = nullptr;  // [n_t][d]
+  // respaced sampling (tamf_set_timestep_map): row i = temb[map[i]], i = the loop's own step index; the loop's kernels read this table
+  // instead of temb while a map is set (a single evaluation - tamf_denoise - always indexes temb with the caller's timesteps)
+  float* temb_loop = nullptr;
+  int temb_loop_cap = 0;
+  bool tmap_on = false, in_loop = false;
+  int tmap_max = -1;
   OperandBuf Wt1_f32, Wt2_f32;
   float *bt1 = nullptr, *bt2 = nullptr;
   // conditioning (tamf_misc.h, prefix_rows_kernel / cobj_kernel): transposed weights W^T [K][d]; WcT / bc = input_merge.0[:, d:2d] composed with
@@ -1192,6 +1198,11 @@ extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c
     ctx->h_sigma[i] = expf(0.5f * (float)logvar[i]);  // th.exp(0.5 * log_variance) on float32 (:459)
   }
   ctx->n_steps = n_steps;
+  if (ctx->tmap_on) {  // a new schedule is a new sampler: its timestep map (if any) is set after it
+    TRY(retire_graph(ctx));
+    ctx->tmap_on = false;
+    ctx->tmap_max = -1;
+  }
   if (n_steps > ctx->sched_cap) {  // (re)allocated only when a longer schedule arrives; a captured graph holds these pointers
     TRY(retire_graph(ctx));
     const int cap = std::max(n_steps, 1000);
@@ -1205,6 +1216,46 @@ extern "C" int tamf_set_schedule(tamf_ctx* ctx, int32_t n_steps, const double* c
   HIPCHK(ctx, hipMemcpy(ctx->c1, ctx->h_c1.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(ctx->c2, ctx->h_c2.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(ctx->sigma, ctx->h_sigma.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int tamf_set_timestep_map(tamf_ctx* ctx, int32_t n_steps, const int32_t* map_host) {
+  TAMF_LAUNCH_LOCK;
+  if (!ctx) return fail(ctx, TAMF_ERR_INVALID, "null ctx");
+  if (!ctx->finalized || !ctx->has_t) return fail(ctx, TAMF_ERR_STATE, "tamf_set_timestep_map needs a G context with finalised weights");
+  if (ctx->n_steps <= 0 || n_steps != ctx->n_steps) return fail(ctx, TAMF_ERR_STATE, "tamf_set_timestep_map: set the schedule of the same length first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  TRY(retire_graph(ctx));  // (a captured loop holds the table pointer of its capture time)
+  if (!map_host) {
+    ctx->tmap_on = false;
+    ctx->tmap_max = -1;
+    return 0;
+  }
+  int mx = -1;
+  for (int i = 0; i < n_steps; ++i) {
+    if (map_host[i] < 0 || map_host[i] >= ctx->n_t)
+      return fail(ctx, TAMF_ERR_INVALID, "timestep map entry " + std::to_string(map_host[i]) + " outside the timestep table (max_timesteps = " + std::to_string(ctx->n_t) + ")");
+    if (i && map_host[i] <= map_host[i - 1]) return fail(ctx, TAMF_ERR_INVALID, "timestep map must be strictly increasing (respace.py:76-82)");
+    mx = std::max(mx, (int)map_host[i]);
+  }
+  if (n_steps > ctx->temb_loop_cap) {
+    const int cap = std::max(n_steps, 1000);
+    TRY(dev_alloc(ctx, (void**)&ctx->temb_loop, (size_t)cap * ctx->d * 4));
+    ctx->temb_loop_cap = cap;
+  }
+  int* map_dev = nullptr;
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMalloc((void**)&map_dev, (size_t)n_steps * 4));
+  hipError_t e = hipMemcpy(map_dev, map_host, (size_t)n_steps * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)n_steps * ctx->d), dim3(256), 0, nullptr, ctx->temb_loop, ctx->temb, map_dev, n_steps, ctx->d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(map_dev);
+  HIPCHK(ctx, e);
+  ctx->tmap_on = true;
+  ctx->tmap_max = mx;
   return 0;
 }
 
@@ -1363,7 +1414,8 @@ static int enqueue_step(tamf_ctx* ctx, hipStream_t st, const EpiHead<Op>& head_i
     hipStream_t sk = TAMF_NEXT_STREAM;
     GemmArgs<Op> ga{(const E*)ctx->h1_op.p, d, (const E*)ctx->Wm2.p, d, B * T, d, d, 0};
     // (+ the prefix and pad rows of every clip, written by the tile that holds the clip's first frame)
-    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_st, d, T, Sp, P, ctx->pstatic, ctx->temb, ctx->tcur, ctx->has_t, S, t_off, {ctx->Wm2.inv_scale, ctx->status}};
+    const float* temb_now = (ctx->in_loop && ctx->tmap_on) ? ctx->temb_loop : ctx->temb;
+    EpiSeqRows<Op> ep{ctx->bm2, ctx->pe + (long)P * d, d, ctx->X, (E*)ctx->X_st, d, T, Sp, P, ctx->pstatic, temb_now, ctx->tcur, ctx->has_t, S, t_off, {ctx->Wm2.inv_scale, ctx->status}};
     hipError_t es = hipSuccess;
     if (small_m_launch<Op>(ga, ep, sk, &es)) HIPCHK(ctx, es);
     else HIPCHK(ctx, gemm128<Op>(ga, ep, sk));
@@ -1568,6 +1620,11 @@ static int loop_impl(tamf_ctx* ctx, const float* noise, uint64_t seed, int64_t c
                      (long long)clip_base, ctx->status);
   hipLaunchKernelGGL(set_t_kernel, grid1d(B), dim3(256), 0, st, ctx->tcur, (const long long*)nullptr, N - 1, B, ctx->n_t > 0 ? ctx->n_t : 1);
   EpiHead<Op> h = make_head<Op>(ctx, HEAD_DDPM);
+  struct InLoop {  // the step's timestep-embedding table is the respaced one (if a map is set) while the LOOP enqueues or captures
+    tamf_ctx* c;
+    explicit InLoop(tamf_ctx* c_) : c(c_) { c->in_loop = true; }
+    ~InLoop() { c->in_loop = false; }
+  } in_loop_(ctx);
   hipLaunchKernelGGL(set_loop_params_kernel, dim3(1), dim3(64), 0, st, ctx->loop_params, noise, dump, (long)B * ctx->F * T,
                      (unsigned long long)seed, (long long)clip_base);
   if (!use_graph) {

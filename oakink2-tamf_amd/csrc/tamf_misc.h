@@ -79,6 +79,11 @@ __global__ void set_t_kernel(int* tcur, const long long* t_dev, int uniform_t, i
   t = t < 0 ? 0 : (t >= n_t ? n_t - 1 : t);
   tcur[i] = (int)t;
 }
+// rows of the timestep-embedding table in the order a respaced sampler visits them: dst[i] = src[map[i]]  (tamf_set_timestep_map)
+__global__ void gather_rows_kernel(float* dst, const float* src, const int* map, int n, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)n * d) dst[i] = src[(long)map[i / d] * d + i % d];
+}
 // end of a captured graph of G steps: the step counter moves on by G
 __global__ void advance_t_kernel(int* tcur, int B, int G) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

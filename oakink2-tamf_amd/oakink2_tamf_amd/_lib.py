@@ -196,7 +196,7 @@ def load_from(path: str) -> ctypes.CDLL:
 
 EXPORTS = [  # include/tamf_hip.h: what libtamf_hip.so exports, nothing else
     "tamf_ctx_create", "tamf_ctx_resize", "tamf_ctx_destroy", "tamf_last_error", "tamf_load_weight", "tamf_finalize_weights",
-    "tamf_set_schedule", "tamf_set_cond", "tamf_set_cond_ragged", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
+    "tamf_set_schedule", "tamf_set_timestep_map", "tamf_set_cond", "tamf_set_cond_ragged", "tamf_denoise", "tamf_ddpm_step", "tamf_sample_loop", "tamf_refine",
     "tamf_pose_decode", "tamf_h2o_dist", "tamf_contact_min_dist", "tamf_mesh_contains", "tamf_transform_points", "tamf_vertex_normals",
     "tamf_get_status_flags", "tamf_step_kernel_count", "tamf_loop_stats", "tamf_step_profile", "tamf_refine_profile",
 ]

@@ -60,6 +60,8 @@ def _bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.tamf_load_weight.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
     L.tamf_finalize_weights.argtypes = [c_void_p, c_int32, c_void_p]
     L.tamf_set_schedule.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
+    if hasattr(L, "tamf_set_timestep_map"):  # (round 6; absent from older A/B builds)
+        L.tamf_set_timestep_map.argtypes = [c_void_p, c_int32, c_void_p]
     L.tamf_set_cond.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     if hasattr(L, "tamf_set_cond_ragged"):  # (absent only from older A/B builds loaded by tools/ through _lib.load_from)
         L.tamf_ctx_resize.argtypes = [c_void_p, c_int32, c_int32]
@@ -234,7 +236,9 @@ class TamfContext:
             note = L.tamf_last_error(self._h)
             raise TamfRangeError(note.decode() if note else "f16x3: a weight tensor's dynamic range exceeds the split-fp16 format")
 
-    def set_schedule(self, coef1: np.ndarray, coef2: np.ndarray, log_variance_clipped: np.ndarray):
+    def set_schedule(self, coef1: np.ndarray, coef2: np.ndarray, log_variance_clipped: np.ndarray, timestep_map=None):
+        """The float64 posterior tables of the sampler; `timestep_map` (respaced samplers, respace.py:60-119): step i of the loop
+        evaluates the denoiser at timestep_map[i] of the base process (None = identity)."""
         c1 = np.ascontiguousarray(coef1, dtype=np.float64)
         c2 = np.ascontiguousarray(coef2, dtype=np.float64)
         lv = np.ascontiguousarray(log_variance_clipped, dtype=np.float64)
@@ -242,6 +246,12 @@ class TamfContext:
         self.n_steps = int(c1.shape[0])
         _check(self._L.tamf_set_schedule(self._h, self.n_steps, c1.ctypes.data_as(c_void_p), c2.ctypes.data_as(c_void_p),
                                        lv.ctypes.data_as(c_void_p)), self._h)
+        if timestep_map is not None:
+            tm = np.ascontiguousarray(timestep_map, dtype=np.int32)
+            assert tm.shape == (self.n_steps,), (tm.shape, self.n_steps)
+            if not np.array_equal(tm, np.arange(self.n_steps, dtype=np.int32)):
+                with torch.cuda.device(self.device):
+                    _check(self._L.tamf_set_timestep_map(self._h, self.n_steps, tm.ctypes.data_as(c_void_p)), self._h, self._L)
 
     # -- conditioning -------------------------------------------------------------------------
     def set_cond(self, text_embedding: Optional[torch.Tensor], hand_side: Sequence, shape: torch.Tensor,

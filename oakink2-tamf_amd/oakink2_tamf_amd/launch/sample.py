@@ -124,6 +124,8 @@ def parse_args(argv: List[str], prog: str = "oakink2_tamf_amd.launch.sample"):
                     help="MFMA operand format (default: the package-wide default, fp32-equivalent split fp16 with range fallback to f32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--diffusion_steps", type=int, default=1000)
+    ap.add_argument("--timestep_respacing", default="", help="this build's own flag: sample over a subset of the trained timesteps "
+                    "(section counts of the reference's space_timesteps, e.g. 100 or ddim50; default: every step, as the reference)")
     known, rest = ap.parse_known_args(argv)
     dotted = {}
     i = 0
@@ -328,7 +330,8 @@ def sample_worker(worker_id: int, num_worker: int, device_id: int, cfg: Dict, kn
     torch.manual_seed(known.seed)  # without a checkpoint every worker draws the SAME random weights (the split of the clips must not change a sample)
     model = InterationSegmentMDM(**mc, precision=known.precision, max_batch=min(bs, max(stop - start, 1)), max_frames=T,
                                  load_clip=bool(getattr(clips, "needs_clip", False)), per_clip_object_mean=clips.ragged).to(device)
-    diffusion = create_gaussian_diffusion(diffusion_steps=known.diffusion_steps, noise_schedule="cosine")
+    diffusion = create_gaussian_diffusion(diffusion_steps=known.diffusion_steps, noise_schedule="cosine",
+                                          timestep_respacing=known.timestep_respacing)
     wpath = cfg["debug"].get("model_weight_filepath")
     if wpath:
         state_dict = torch.load(wpath, map_location="cpu")

@@ -300,7 +300,11 @@ class InterationSegmentMDM(_HipDenoiserBase):
         """The whole p_sample_loop as one library call (hipGraph replay); see GaussianDiffusion.p_sample_loop."""
         B, F, _, T = shape
         N = diffusion.num_timesteps
-        self._max_timesteps = max(self._max_timesteps, N)
+        # (a respaced sampler visits timesteps of its BASE process: the timestep table must reach them)
+        n_table = max(N, int(getattr(diffusion, "original_num_steps", N)))
+        if n_table > self._max_timesteps:
+            self._max_timesteps = n_table
+            self._ctx_dirty = True
         draws = None
         while True:
             res, draws = self._fused_loop_once(diffusion, shape, x_T, batch, dump_steps, noise_source, seed, clip_id_base, draws)
@@ -312,11 +316,12 @@ class InterationSegmentMDM(_HipDenoiserBase):
         N = diffusion.num_timesteps
         ctx = self._context(B, T)
         # keyed on the coefficient values themselves (a new diffusion object at a recycled id must not hit)
+        tmap = tuple(getattr(diffusion, "timestep_map", ())) if getattr(diffusion, "respaced", False) else None
         skey = (N, diffusion.posterior_mean_coef1.tobytes(), diffusion.posterior_mean_coef2.tobytes(),
-                diffusion.posterior_log_variance_clipped.tobytes())
+                diffusion.posterior_log_variance_clipped.tobytes(), tmap)
         if self._sched_key != skey:
             ctx.set_schedule(diffusion.posterior_mean_coef1, diffusion.posterior_mean_coef2,
-                             diffusion.posterior_log_variance_clipped)
+                             diffusion.posterior_log_variance_clipped, timestep_map=tmap)
             self._sched_key = skey
         self._set_cond(ctx, batch, self._text_embedding(batch))
         dev = ctx.device

@@ -146,7 +146,10 @@ def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfini
 
 
 def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_noise: bool, dump_steps=None, sd_fn=O.det_state_dict,
-                 cond_fn=O.det_cond):
+                 cond_fn=O.det_cond, respacing=None, base_steps=None):
+    """respacing (round 6): the reference's SpacedDiffusion over a SUBSET of `base_steps` timesteps (respace.py:60-119; its factory
+    hard-codes the full set, so the class is constructed directly with the factory's other arguments); `steps` is then the number of
+    kept steps."""
     from oakink2_tamf.model.diffusion_util import create_gaussian_diffusion
     from oakink2_tamf.model.diffusion import gaussian_diffusion as gd
 
@@ -155,7 +158,15 @@ def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_nois
     cond = cond_fn(B, T, tag=f"{name}/c", arch=arch)
     batch = _ref_batch(cond, m)
     shape = (B, arch.input_dim, 1, T)
-    dif = create_gaussian_diffusion(diffusion_steps=steps, noise_schedule="cosine")
+    if respacing is None:
+        dif = create_gaussian_diffusion(diffusion_steps=steps, noise_schedule="cosine")
+    else:
+        from oakink2_tamf.model.diffusion.respace import SpacedDiffusion, space_timesteps
+
+        dif = SpacedDiffusion(use_timesteps=space_timesteps(base_steps, respacing), betas=gd.get_named_beta_schedule("cosine", base_steps, 1.0),
+                              model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                              loss_type=gd.LossType.MSE, rescale_timesteps=False)
+        assert dif.num_timesteps == steps, (dif.num_timesteps, steps)
 
     calls = {"k": 0}
     draws = []
@@ -191,8 +202,18 @@ def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_nois
     finally:
         gd.th = real_th
     assert calls["k"] == steps + 1
-    tab = O.make_tables(steps, "cosine")
-    fix = {"B": B, "T": T, "steps": steps}
+    if respacing is None:
+        tab = O.make_tables(steps, "cosine")
+        fix = {"B": B, "T": T, "steps": steps}
+    else:
+        tab = O.make_tables(base_steps, "cosine", O.space_timesteps(base_steps, respacing))
+        assert tab.timestep_map == list(dif.timestep_map)
+        fix = {"B": B, "T": T, "steps": steps, "base_steps": base_steps, "respacing": np.array(respacing),
+               "timestep_map": np.array(dif.timestep_map, dtype=np.int64)}
+        for k in ("betas", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped"):
+            ref_t = np.asarray(getattr(dif, k), dtype=np.float64)
+            print(f"respaced schedule {name} {k}: oracle-vs-reference max abs err {np.max(np.abs(ref_t - getattr(tab, k))):.3e}")
+            fix[f"tab/{k}"] = ref_t
     fix.update({f"cond/{k}": v for k, v in _cond_np(cond).items()})
     if dump_steps is not None:
         dump_ref = res
@@ -679,6 +700,16 @@ def capture_trained_all():
                      sd_fn=trained_state_dict, cond_fn=trained_cond)
 
 
+def capture_respaced():
+    """The reference's SpacedDiffusion over 50 of the 1000 timesteps (space_timesteps(1000, "50")) and over the DDIM stride of 100
+    ("ddim100"), trained weights: ancestral sampling on a strided subset - the denoiser is evaluated at timestep_map[t]."""
+    arch = TRAINED["trained_hd128"][0]
+    capture_loop("trained_hd128_respaced50_b2_t40", arch, B=2, T=40, steps=50, store_noise=False, dump_steps=[0, 24, 48, 49],
+                 sd_fn=trained_state_dict, cond_fn=trained_cond, respacing="50", base_steps=1000)
+    capture_loop("trained_hd128_respaced_ddim100_b2_t40", arch, B=2, T=40, steps=100, store_noise=False, dump_steps=[0, 49, 98, 99],
+                 sd_fn=trained_state_dict, cond_fn=trained_cond, respacing="ddim100", base_steps=1000)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "the reference is only present in the build container"
     _install_clip_stub()
@@ -707,6 +738,7 @@ def main():
     capture_stress()
     capture_stress_dc()
     capture_trained_all()
+    capture_respaced()
     capture_refine("tiny_r", O.ARCH_TINY_R, B=2, T=16)
     capture_refine("arch_refine", O.ARCH_REFINE, B=2, T=24)
     capture_geometry()

@@ -87,6 +87,7 @@ class DiffusionTables:
     posterior_mean_coef2: np.ndarray
     sqrt_alphas_cumprod: np.ndarray
     sqrt_one_minus_alphas_cumprod: np.ndarray
+    timestep_map: Optional[List[int]] = None  # base timestep of every step (make_tables; None = identity)
 
 
 def _tables_from_betas(betas: np.ndarray) -> DiffusionTables:
@@ -112,8 +113,35 @@ def _tables_from_betas(betas: np.ndarray) -> DiffusionTables:
     )
 
 
-def make_tables(steps: int, schedule: str = "cosine") -> DiffusionTables:
-    """model/diffusion_util.py:5-31 -> SpacedDiffusion(use_timesteps=all) (respace.py:69-83)."""
+def space_timesteps(num_timesteps: int, section_counts) -> List[int]:
+    """model/diffusion/respace.py:8-57: the kept timesteps of a respaced process, sorted ("N" / "a,b,c" section counts, or "ddimN")."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return list(range(0, num_timesteps, stride))
+            raise ValueError("cannot create exactly that many steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(section_counts))
+    start, out = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            out.append(start + round(cur))
+            cur += stride
+        start += size
+    return sorted(set(out))
+
+
+def make_tables(steps: int, schedule: str = "cosine", use_timesteps: Optional[Sequence[int]] = None) -> DiffusionTables:
+    """model/diffusion_util.py:5-31 -> SpacedDiffusion (respace.py:69-83): use_timesteps = None keeps every timestep (what the
+    launchers run); a subset re-derives the betas of the kept steps from the base process' cumulative alphas.  The returned tables
+    carry `timestep_map` (attribute set below): the base timestep of every kept step."""
     if schedule == "cosine":
         base_betas = cosine_betas(steps)
     elif schedule == "linear":
@@ -121,12 +149,17 @@ def make_tables(steps: int, schedule: str = "cosine") -> DiffusionTables:
     else:
         raise NotImplementedError(f"unknown beta schedule: {schedule}")
     base = _tables_from_betas(base_betas)
+    keep = set(range(steps)) if use_timesteps is None else set(int(t) for t in use_timesteps)
     last = 1.0
-    new_betas = []
-    for ac in base.alphas_cumprod:  # every timestep is kept
-        new_betas.append(1 - ac / last)
-        last = ac
-    return _tables_from_betas(np.array(new_betas))
+    new_betas, tmap = [], []
+    for i, ac in enumerate(base.alphas_cumprod):
+        if i in keep:
+            new_betas.append(1 - ac / last)
+            last = ac
+            tmap.append(i)
+    tab = _tables_from_betas(np.array(new_betas))
+    tab.timestep_map = tmap
+    return tab
 
 
 # --------------------------------------------------------------------------------------
@@ -458,8 +491,10 @@ def sample_loop(
     indices = list(range(N))[::-1]
     if n_steps is not None:
         indices = indices[:n_steps]
+    tmap = getattr(tab, "timestep_map", None)
     for k, i in enumerate(indices):
-        t = torch.full((B,), i, dtype=torch.long)
+        # (_WrappedModel, respace.py:114-119: the denoiser sees the BASE process' timestep of step i)
+        t = torch.full((B,), i if tmap is None else tmap[i], dtype=torch.long)
         x0 = denoiser_forward(sd, arch, x, t, cond, dtype=dtype)
         x = ddpm_step(tab, x, x0, i, draw(k + 1).to(dtype))
         if dump is not None:

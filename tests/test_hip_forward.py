@@ -346,3 +346,65 @@ def test_trained_loop_1000(name, prec):
     if prec == "f16x3":
         assert ctx.status_flags() == 0
     ctx.close()
+
+
+# ---- respaced sampling (round 6): the fused loop with a timestep map (tamf_set_timestep_map) ---------------------------------------------
+RESPACED = {"trained_hd128_respaced50_b2_t40": 50, "trained_hd128_respaced_ddim100_b2_t40": 100}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("lname", list(RESPACED))
+def test_respaced_loop_golden(lname, prec):
+    """The reference's SpacedDiffusion over 50 / 100 of 1000 timesteps (respace.py:60-119), trained weights: the hipGraph loop with the
+    respaced tables and the timestep map, against the reference's states - and the map must matter (identity map: far off)."""
+    from oracle import det
+
+    steps = RESPACED[lname]
+    fix = load_golden(f"loop_{lname}.npz")
+    arch = trained_arch("trained_hd128")
+    sd, _ = load_trained_sd("trained_hd128")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 40)
+    draws = torch.from_numpy(np.stack([det.det_normal(det.step_noise_tag(f"{lname}/eps", k), shape) for k in range(steps + 1)]))
+    ctx = _make_ctx(arch, sd, 2, 40, prec, n_steps=steps)
+    tmap = fix["timestep_map"]
+    ctx.set_schedule(fix["tab/posterior_mean_coef1"], fix["tab/posterior_mean_coef2"], fix["tab/posterior_log_variance_clipped"], timestep_map=tmap)
+    _set_cond(ctx, cond)
+    for use_graph in (True, False):
+        out, dump = ctx.sample_loop(noise=draws, dump=True, use_graph=use_graph)
+        worst = 0.0
+        for s_ in fix["dump_steps"]:
+            ref = fix[f"dump/{int(s_)}"]
+            worst = max(worst, float(np.abs(dump[int(s_)].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())))
+        assert worst < LOOP_TOL[prec], (lname, prec, use_graph, worst)
+    print(f"respaced loop[{lname}, {prec}]: max|err| / max(1, |ref|max) = {worst:.3e}")
+    # one evaluation is not touched by the map: the caller's timesteps index the table directly (what _WrappedModel hands the model)
+    x = draws[0]
+    t = torch.tensor([int(tmap[-1]), int(tmap[3])])
+    from oracle import mdm_oracle as O
+
+    ref1 = O.denoiser_forward(sd, arch, x, t, cond)
+    assert float((ctx.denoise(x, t).cpu() - ref1).abs().max()) < FWD_TOL[prec] * max(1.0, float(ref1.abs().max()))
+    # and with the map cleared (a new schedule) the same tables give another sample: the map is what the loop follows
+    ctx.set_schedule(fix["tab/posterior_mean_coef1"], fix["tab/posterior_mean_coef2"], fix["tab/posterior_log_variance_clipped"])
+    plain = ctx.sample_loop(noise=draws).cpu().numpy()
+    assert np.abs(plain - fix["final"]).max() > 1e-2
+    ctx.close()
+
+
+def test_timestep_map_error_paths():
+    from oakink2_tamf_amd.hip_backend import TamfError
+
+    arch = trained_arch("trained_tiny")
+    sd, _ = load_trained_sd("trained_tiny")
+    from oracle import mdm_oracle as O
+
+    tab = O.make_tables(1000, "cosine", O.space_timesteps(1000, "10"))
+    ctx = _make_ctx(arch, sd, 1, 8, "f32", n_steps=10)
+    args = (tab.posterior_mean_coef1, tab.posterior_mean_coef2, tab.posterior_log_variance_clipped)
+    with pytest.raises(TamfError, match="outside the timestep table"):
+        ctx.set_schedule(*args, timestep_map=[0, 1, 2, 3, 4, 5, 6, 7, 8, 5000])
+    with pytest.raises(TamfError, match="strictly increasing"):
+        ctx.set_schedule(*args, timestep_map=[0, 5, 4, 30, 40, 50, 60, 70, 80, 90])
+    ctx.set_schedule(*args, timestep_map=tab.timestep_map)
+    ctx.close()

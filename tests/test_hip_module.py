@@ -408,3 +408,36 @@ def test_module_text_branch_with_a_stub_clip(monkeypatch):
             sys.modules["clip"] = had
         else:
             sys.modules.pop("clip", None)
+
+
+def test_respaced_p_sample_loop_through_the_module_contract():
+    """create_gaussian_diffusion(1000, "cosine", timestep_respacing="20").p_sample_loop(model, ...): the fused hipGraph loop (timestep map
+    in the library) == the per-step path (the reference's _WrappedModel around the HIP forward) == the oracle fed the same draws"""
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+    from oracle import mdm_oracle as O
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="resp/w")
+    B, T = 2, 16
+    cond = O.det_cond(B, T, tag="resp/c", arch=arch)
+    batch = {k: (v.cuda() if hasattr(v, "cuda") else v) for k, v in cond.items()}
+    m = _module(arch, sd, "f32")
+    dif = create_gaussian_diffusion(1000, "cosine", timestep_respacing="20")
+    assert dif.num_timesteps == 20 and dif.respaced
+    shape = (B, 99, 1, T)
+    torch.manual_seed(5)
+    fused = dif.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"batch": batch}, noise_source="torch_cpu")
+    torch.manual_seed(5)
+    draws = [torch.randn(*shape) for _ in range(21)]
+    tab = O.make_tables(1000, "cosine", O.space_timesteps(1000, "20"))
+    ref = O.sample_loop(sd, arch, tab, cond, shape, lambda k: draws[k])
+    assert float((fused.cpu() - ref).abs().max()) < 1e-5
+    # the per-step path (a Python hook forces it): the wrapper maps t -> timestep_map[t] before the HIP forward
+    torch.manual_seed(5)
+    x_T = torch.randn(*shape)
+    torch.manual_seed(6)
+    generic = dif.p_sample_loop(m, shape, noise=x_T.cuda(), clip_denoised=False, denoised_fn=lambda v: v, model_kwargs={"batch": batch})
+    torch.manual_seed(6)
+    eps = [torch.randn(*shape, device="cuda").cpu() for _ in range(20)]
+    ref2 = O.sample_loop(sd, arch, tab, cond, shape, lambda k: x_T if k == 0 else eps[k - 1])
+    assert float((generic.cpu() - ref2).abs().max()) < 1e-5

@@ -252,3 +252,43 @@ def test_trained_loop_1000(name):
     for s_ in fix["dump_steps"]:
         ref = fix[f"dump/{int(s_)}"]
         np.testing.assert_allclose(dump[int(s_)].numpy(), ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+# ---- respaced sampling (round 6): SpacedDiffusion over a SUBSET of the timesteps, respace.py:60-119 -----------------------------------
+RESPACED = {"trained_hd128_respaced50_b2_t40": ("50", 50), "trained_hd128_respaced_ddim100_b2_t40": ("ddim100", 100)}
+
+
+@pytest.mark.parametrize("lname", list(RESPACED))
+def test_respaced_schedule_and_loop_match_reference(lname):
+    """the reference's SpacedDiffusion(use_timesteps = space_timesteps(1000, ...)): kept timesteps, re-derived float64 tables, and its
+    p_sample_loop with the denoiser evaluated at timestep_map[t] - the oracle's restatement and the host mirror's factory extension"""
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+
+    respacing, steps = RESPACED[lname]
+    fix = load_golden(f"loop_{lname}.npz")
+    assert str(fix["respacing"]) == respacing and int(fix["steps"]) == steps and int(fix["base_steps"]) == 1000
+    tab = O.make_tables(1000, "cosine", O.space_timesteps(1000, respacing))
+    dif = create_gaussian_diffusion(1000, "cosine", timestep_respacing=respacing)
+    assert tab.timestep_map == list(fix["timestep_map"]) == list(dif.timestep_map) and dif.num_timesteps == steps and dif.respaced
+    for k in ("betas", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped"):
+        np.testing.assert_allclose(getattr(tab, k), fix[f"tab/{k}"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(getattr(dif, k), fix[f"tab/{k}"], rtol=0, atol=1e-15)
+    arch = trained_arch("trained_hd128")
+    sd, _ = load_trained_sd("trained_hd128")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 40)
+    dump = []
+    O.sample_loop(sd, arch, tab, cond, shape, lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{lname}/eps", k), shape)), dump=dump)
+    for s_ in fix["dump_steps"]:
+        ref = fix[f"dump/{int(s_)}"]
+        np.testing.assert_allclose(dump[int(s_)].numpy(), ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_identity_respacing_is_the_launchers_diffusion():
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+
+    a, b = create_gaussian_diffusion(50, "cosine"), create_gaussian_diffusion(50, "cosine", timestep_respacing="50")
+    assert not a.respaced and not b.respaced and a.timestep_map == b.timestep_map == list(range(50))
+    np.testing.assert_array_equal(a.posterior_mean_coef1, b.posterior_mean_coef1)
+    with pytest.raises(ValueError):
+        create_gaussian_diffusion(50, "cosine", timestep_respacing="60")
