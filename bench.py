@@ -1011,7 +1011,10 @@ def main(argv=None, sampler_factory=None):
             line["other_dtypes"] = other
         if not args.no_torch_baseline and world == 1 and not stub:
             # same-box library yardstick: the reference's own op sequence through PyTorch-ROCm (hipBLASLt / SDPA), after every timed region
-            tb = torch_rocm_baseline(args.arch, sd, cond, B, T, N, dev, check_in)
+            try:
+                tb = torch_rocm_baseline(args.arch, sd, cond, B, T, N, dev, check_in)
+            except Exception as e:  # noqa: BLE001  (a yardstick that cannot run must not take the bench line with it)
+                tb = {"error": f"{type(e).__name__}: {str(e)[:300]}", "variants": {}}
             line["torch_rocm_baseline"] = tb
             mine = {"f32": (line.get("fp32") or {}).get("value"), "bf16": (other.get("bf16") or {}).get("value") if args.dtype != "bf16" else value,
                     args.dtype: value}
