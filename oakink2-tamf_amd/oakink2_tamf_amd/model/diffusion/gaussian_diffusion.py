@@ -96,14 +96,21 @@ class GaussianDiffusion:
         mean, var, logvar = self.q_posterior_mean_variance(pred_xstart, x, t)
         return {"mean": mean, "variance": var, "log_variance": logvar, "pred_xstart": pred_xstart}
 
+    def condition_mean(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
+        """mean of the previous step under a guidance term: cond_fn(x, t, **model_kwargs) = grad log p(y | x) (reference :346-357,
+        Sohl-Dickstein et al. 2015): new mean = mean + variance * gradient.  Never passed by the launchers; a per-step Python hook,
+        so the loop runs on the per-step path (HIP forward + torch update)."""
+        gradient = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        return p_mean_var["mean"].float() + p_mean_var["variance"] * gradient.float()
+
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, const_noise=False):
-        if cond_fn is not None:
-            raise NotImplementedError("cond_fn guidance is not used by the MF-MDM sampling path")
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
         noise = th.randn_like(x)
         if const_noise:
             noise = noise[[0]].repeat(x.shape[0], 1, 1, 1)
         nonzero_mask = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        if cond_fn is not None:
+            out["mean"] = self.condition_mean(cond_fn, out, x, t, model_kwargs=model_kwargs)
         sample = out["mean"] + nonzero_mask * th.exp(0.5 * out["log_variance"]) * noise
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 

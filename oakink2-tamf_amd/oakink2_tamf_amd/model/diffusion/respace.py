@@ -68,6 +68,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def p_mean_variance(self, model, *args, **kwargs):
         return super().p_mean_variance(self._wrap_model(model), *args, **kwargs)
 
+    def condition_mean(self, cond_fn, *args, **kwargs):  # (the guidance function sees the base process' timesteps too, :91-92)
+        return super().condition_mean(self._wrap_model(cond_fn), *args, **kwargs)
+
 
 class _WrappedModel:
     """model(x, ts) -> model(x, timestep_map[ts]) (reference :107-119; rescale_timesteps is never set by the factory)"""
@@ -82,6 +85,7 @@ class _WrappedModel:
 
     def parameters(self):
         return self.model.parameters()
+
 
     def __call__(self, x, ts, **kwargs):
         import torch as th

@@ -19,6 +19,7 @@ import torch
 
 from . import det
 from . import mdm_oracle as O
+from .fixtures import guidance_fn
 
 REF_SRC = "/root/reference/src"
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -146,7 +147,7 @@ def capture_forward(name: str, arch: O.Arch, B: int, T: int, ts, nobj=2, nonfini
 
 
 def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_noise: bool, dump_steps=None, sd_fn=O.det_state_dict,
-                 cond_fn=O.det_cond, respacing=None, base_steps=None):
+                 cond_fn=O.det_cond, respacing=None, base_steps=None, guide=None):
     """respacing (round 6): the reference's SpacedDiffusion over a SUBSET of `base_steps` timesteps (respace.py:60-119; its factory
     hard-codes the full set, so the class is constructed directly with the factory's other arguments); `steps` is then the number of
     kept steps."""
@@ -197,7 +198,7 @@ def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_nois
     try:
         with torch.no_grad():
             res = dif.p_sample_loop(
-                m, shape, clip_denoised=False, model_kwargs={"batch": batch}, dump_steps=dump_steps
+                m, shape, clip_denoised=False, model_kwargs={"batch": batch}, dump_steps=dump_steps, cond_fn=guide
             )
     finally:
         gd.th = real_th
@@ -218,7 +219,7 @@ def capture_loop(name: str, arch: O.Arch, B: int, T: int, steps: int, store_nois
     if dump_steps is not None:
         dump_ref = res
         dump_mine: list = []
-        O.sample_loop(sd, arch, tab, cond, shape, draw, dump=dump_mine)
+        O.sample_loop(sd, arch, tab, cond, shape, draw, dump=dump_mine, cond_fn=guide)
         for j, s in enumerate(dump_steps):
             e = (dump_ref[j] - dump_mine[s]).abs().max().item()
             print(f"loop {name}: dump step {s}: |ref-oracle32| = {e:.3e}")
@@ -708,6 +709,9 @@ def capture_respaced():
                  sd_fn=trained_state_dict, cond_fn=trained_cond, respacing="50", base_steps=1000)
     capture_loop("trained_hd128_respaced_ddim100_b2_t40", arch, B=2, T=40, steps=100, store_noise=False, dump_steps=[0, 49, 98, 99],
                  sd_fn=trained_state_dict, cond_fn=trained_cond, respacing="ddim100", base_steps=1000)
+    # classifier-style guidance (cond_fn, gaussian_diffusion.py:346-357,453-454) on the respaced process: p_sample adds variance * gradient
+    capture_loop("trained_tiny_guided_respaced20_b2_t40", TRAINED["trained_tiny"][0], B=2, T=40, steps=20, store_noise=False,
+                 dump_steps=[0, 10, 18, 19], sd_fn=trained_state_dict, cond_fn=trained_cond, respacing="20", base_steps=1000, guide=guidance_fn)
 
 
 def main():

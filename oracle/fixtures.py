@@ -195,3 +195,9 @@ def synthetic_object_mesh(obj_id: str):
 
 def synthetic_sample_pose_repr(dir_name: str, sample_id: int, T: int = 160):
     return det.det_normal(f"gsample/{dir_name}/{sample_id}", (T, 99)).astype(np.float32)
+
+
+def guidance_fn(x, t, **kwargs):
+    """the cond_fn of the guided fixture (capture_golden.capture_respaced) and of the tests that replay it: a pull towards a t-dependent
+    target - it uses BOTH arguments, so a wrong timestep map shows"""
+    return -0.5 * x + 0.2 * (t.float() / 1000.0).view(-1, 1, 1, 1)

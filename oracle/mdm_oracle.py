@@ -453,7 +453,8 @@ def refine_forward(
 # --------------------------------------------------------------------------------------
 
 
-def ddpm_step(tab: DiffusionTables, x_t: torch.Tensor, x0_hat: torch.Tensor, i: int, noise: torch.Tensor) -> torch.Tensor:
+def ddpm_step(tab: DiffusionTables, x_t: torch.Tensor, x0_hat: torch.Tensor, i: int, noise: torch.Tensor,
+              guidance: Optional[torch.Tensor] = None) -> torch.Tensor:
     """p_sample with START_X / FIXED_SMALL / clip_denoised=False
     (gaussian_diffusion.py:209-229,273-320,412-460; tables cast float64 -> float32 at :1275)."""
     dt = x_t.dtype
@@ -465,6 +466,8 @@ def ddpm_step(tab: DiffusionTables, x_t: torch.Tensor, x0_hat: torch.Tensor, i: 
     c2 = cast(tab.posterior_mean_coef2[i])
     logvar = cast(tab.posterior_log_variance_clipped[i])
     mean = c1 * x0_hat + c2 * x_t
+    if guidance is not None:  # condition_mean (gaussian_diffusion.py:346-357): mean + posterior_variance[t] * grad log p(y | x)
+        mean = mean.float() + cast(tab.posterior_variance[i]) * guidance.float()
     nonzero = 0.0 if i == 0 else 1.0
     return mean + nonzero * torch.exp(0.5 * logvar) * noise
 
@@ -480,6 +483,7 @@ def sample_loop(
     n_steps: Optional[int] = None,
     dump: Optional[List[torch.Tensor]] = None,
     unhoisted: bool = True,
+    cond_fn: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None,
 ) -> torch.Tensor:
     """p_sample_loop / p_sample_loop_progressive (gaussian_diffusion.py:506-640): x_T = draw(0), then for
     i = N-1 .. 0: x <- p_sample(x, i) with eps_i = draw(k), k = 1.. in call order (one draw per step,
@@ -496,7 +500,8 @@ def sample_loop(
         # (_WrappedModel, respace.py:114-119: the denoiser sees the BASE process' timestep of step i)
         t = torch.full((B,), i if tmap is None else tmap[i], dtype=torch.long)
         x0 = denoiser_forward(sd, arch, x, t, cond, dtype=dtype)
-        x = ddpm_step(tab, x, x0, i, draw(k + 1).to(dtype))
+        # cond_fn(x_t, t) sees the same (mapped) timesteps as the model (respace.py:91-92)
+        x = ddpm_step(tab, x, x0, i, draw(k + 1).to(dtype), guidance=None if cond_fn is None else cond_fn(x, t))
         if dump is not None:
             dump.append(x.clone())
     return x

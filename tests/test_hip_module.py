@@ -441,3 +441,39 @@ def test_respaced_p_sample_loop_through_the_module_contract():
     eps = [torch.randn(*shape, device="cuda").cpu() for _ in range(20)]
     ref2 = O.sample_loop(sd, arch, tab, cond, shape, lambda k: x_T if k == 0 else eps[k - 1])
     assert float((generic.cpu() - ref2).abs().max()) < 1e-5
+
+
+def test_cond_fn_guidance_on_the_per_step_path():
+    """p_sample_loop(cond_fn=...) (reference :346-357,453-454): a per-step Python hook, so the loop runs HIP forward + torch update; on a
+    respaced process the guidance function sees the base timesteps like the model does.  Equals the oracle fed the same draws."""
+    from oakink2_tamf_amd.model.diffusion_util import create_gaussian_diffusion
+    from oracle import mdm_oracle as O
+    from oracle.fixtures import guidance_fn
+
+    arch = O.ARCH_TINY
+    sd = O.det_state_dict(arch, tag="guide/w")
+    B, T = 2, 16
+    cond = O.det_cond(B, T, tag="guide/c", arch=arch)
+    batch = {k: (v.cuda() if hasattr(v, "cuda") else v) for k, v in cond.items()}
+    m = _module(arch, sd, "f32")
+    dif = create_gaussian_diffusion(1000, "cosine", timestep_respacing="15")
+    shape = (B, 99, 1, T)
+    seen = []
+
+    def guide(x, t, **kw):
+        seen.append(int(t[0]))
+        assert "batch" in kw
+        return guidance_fn(x, t)
+
+    torch.manual_seed(5)
+    x_T = torch.randn(*shape)
+    torch.manual_seed(6)
+    got = dif.p_sample_loop(m, shape, noise=x_T.cuda(), clip_denoised=False, cond_fn=guide, model_kwargs={"batch": batch})
+    torch.manual_seed(6)
+    eps = [torch.randn(*shape, device="cuda").cpu() for _ in range(15)]
+    tab = O.make_tables(1000, "cosine", O.space_timesteps(1000, "15"))
+    ref = O.sample_loop(sd, arch, tab, cond, shape, lambda k: x_T if k == 0 else eps[k - 1], cond_fn=guidance_fn)
+    assert float((got.cpu() - ref).abs().max()) < 1e-5
+    assert seen == tab.timestep_map[::-1]  # the guidance function was called with the BASE process' timesteps, last step first
+    with pytest.raises(NotImplementedError):
+        dif.p_sample_loop(m, shape, clip_denoised=False, cond_fn=guide, cond_fn_with_grad=True, model_kwargs={"batch": batch})

@@ -292,3 +292,26 @@ def test_identity_respacing_is_the_launchers_diffusion():
     np.testing.assert_array_equal(a.posterior_mean_coef1, b.posterior_mean_coef1)
     with pytest.raises(ValueError):
         create_gaussian_diffusion(50, "cosine", timestep_respacing="60")
+
+
+def test_guided_respaced_loop_matches_reference():
+    """cond_fn guidance (gaussian_diffusion.py:346-357,453-454: mean + posterior_variance * grad) on a respaced process (20 of 1000 steps;
+    the guidance function is wrapped like the model, respace.py:91-92): the reference's p_sample_loop(cond_fn=...) vs the oracle"""
+    from oracle.fixtures import guidance_fn
+
+    lname = "trained_tiny_guided_respaced20_b2_t40"
+    fix = load_golden(f"loop_{lname}.npz")
+    tab = O.make_tables(1000, "cosine", O.space_timesteps(1000, "20"))
+    assert tab.timestep_map == list(fix["timestep_map"])
+    arch = trained_arch("trained_tiny")
+    sd, _ = load_trained_sd("trained_tiny")
+    cond = golden_cond(fix)
+    shape = (2, 99, 1, 40)
+    draw = lambda k: torch.from_numpy(det.det_normal(det.step_noise_tag(f"{lname}/eps", k), shape))  # noqa: E731
+    dump = []
+    O.sample_loop(sd, arch, tab, cond, shape, draw, dump=dump, cond_fn=guidance_fn)
+    for s_ in fix["dump_steps"]:
+        ref = fix[f"dump/{int(s_)}"]
+        np.testing.assert_allclose(dump[int(s_)].numpy(), ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    plain = O.sample_loop(sd, arch, tab, cond, shape, draw)
+    assert float((plain - torch.from_numpy(fix["final"])).abs().max()) > 1e-2  # (the guidance term matters)
