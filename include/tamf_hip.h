@@ -19,14 +19,10 @@
  *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors' data_ptr());
  *     "host" pointers are host memory.  The library owns weights, workspaces and hipGraphs.
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns without
- *     synchronising (exceptions are stated per function).  A context is not thread-safe; contexts on
- *     different devices are independent in their data, but the entry points that enqueue kernels take ONE process-wide lock for
- *     their host-side duration (the kernel-selection word of tamf_set_gemm_tuning is process-global and captured graphs bake it
- *     in).  That is microseconds for tamf_denoise / tamf_refine / tamf_set_cond and a graph-replayed tamf_sample_loop, but the whole
- *     call for tamf_finalize_weights (host repack of the checkpoint + a stream synchronisation: ~ 0.1 - 0.5 s) and for
- *     tamf_sample_loop with use_graph = 0 (the enqueue of n_steps x 43 launches): a thread driving another context waits that
- *     long.  The deployment model of the launchers and of bench.py is one PROCESS per GPU (as the reference's), where this
- *     never shows.
+ *     synchronising (exceptions are stated per function).  A context is not thread-safe (one thread per context); distinct contexts
+ *     are independent, also when driven from different threads: libtamf_hip.so takes no process-wide lock in its entry points (rounds
+ *     3 - 5 did, for the process-global kernel-selection word of tamf_set_gemm_tuning - which now exists only in the test build,
+ *     include/tamf_hip_test.h; there the lock is kept).  Only tamf_ctx_create is serialised across threads.
  *   - tensors use the reference's layouts: x / x0 / noise are (B, input_dim, 1, T) float32 contiguous.
  */
 #ifndef TAMF_HIP_H

@@ -166,7 +166,16 @@ static std::mutex g_live_mu;                // (contexts may be created / destro
 // enqueues kernels or touches a context's graph holds this lock for its (host-side, microseconds) duration, and so does
 // tamf_set_gemm_tuning: a thread inside loop_impl never sees a half-updated selection or a graph being destroyed under it.
 static std::recursive_mutex g_launch_mu;
+// Round 6: that serialisation exists ONLY in the hooks build (-DTAMF_TEST_HOOKS), where tamf_set_gemm_tuning can change the words.  The
+// product library has no setter - g_krot / g_sel are constants there - so its entry points take no process-wide lock: contexts are
+// independent (one thread per context, as the header says), the lazily set per-device "kernel attributes prepared" flags and the
+// workgroup-slot table are atomics, and the list of live contexts has its own mutex.  Context creation still serialises (TAMF_STATE_LOCK).
+#ifdef TAMF_TEST_HOOKS
 #define TAMF_LAUNCH_LOCK std::lock_guard<std::recursive_mutex> launch_lock_(g_launch_mu)
+#else
+#define TAMF_LAUNCH_LOCK ((void)0)
+#endif
+#define TAMF_STATE_LOCK std::lock_guard<std::recursive_mutex> state_lock_(g_launch_mu)
 
 static int fail(tamf_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -332,11 +341,11 @@ static inline int krot_for(bool ln_tile) { return g_krot >= 0 ? g_krot : (ln_til
 // resident workgroup slots of the chip for the 2-per-CU tiles (MI355X: 256 CUs); one "round" of a launch.  Per DEVICE (one
 // process-wide word followed the device of the context created last): written by tamf_ctx_create under the launch lock, read for the
 // calling thread's current device - every entry point that enqueues kernels has made its context's device current.
-static int g_wg_slots_dev[64];
+static std::atomic<int> g_wg_slots_dev[64];
 static inline int wg_slots() {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const int v = g_wg_slots_dev[dev & 63];
+  const int v = g_wg_slots_dev[dev & 63].load(std::memory_order_relaxed);
   return v > 0 ? v : 512;
 }
 
@@ -357,16 +366,16 @@ struct GemmLaunch {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   static hipError_t prepare() {  // kernel attributes are per device
-    static bool done[64] = {};
+    static std::atomic<bool> done[64];  // (zero-initialised; relaxed: the attribute calls are idempotent)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     hipError_t e = prepare1<1>();
     if constexpr (CAN_SPLIT) {
       if (e == hipSuccess) e = prepare1<2>();
       if (e == hipSuccess) e = prepare1<4>();
     }
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     return e;
   }
   static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
@@ -420,12 +429,12 @@ template <class Op, int BM, int BN, int NSTG, class Epi, int WGM = 2, int WGN = 
 struct GemmDeepLaunch {
   static constexpr int SMEM = GemmSmemDeep<BM, BN, NSTG>::TOTAL;
   static hipError_t prepare() {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64];  // (zero-initialised; relaxed: the attribute calls are idempotent)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)gemm_deep_kernel<Op, BM, BN, WGM, WGN, NSTG, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     return e;
   }
   static hipError_t launch(const GemmArgs<Op>& ga, const Epi& epi, hipStream_t st) {
@@ -491,13 +500,13 @@ struct ClipLaunch {
   typedef ClipCfg<NSUB, NI, XSUB, Epi::LANE_CHUNK> C;
   static constexpr int CLIP_ROWS_MAX = PARTS * C::MT;  // padded rows of the longest clip these tiles hold
   static hipError_t prepare() {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64];  // (zero-initialised; relaxed: the attribute calls are idempotent)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)clip_gemm_kernel<Op, NSUB, NI, XSUB, Epi>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::BYTES);
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     return e;
   }
   static bool shape_ok(int Sp, int N, int K) {
@@ -815,14 +824,12 @@ extern "C" int tamf_ctx_create(const tamf_arch* arch, int32_t max_batch, int32_t
   if (hipSetDevice(device) != hipSuccess) return bail(fail(ctx, TAMF_ERR_HIP, "hipSetDevice failed"));
   {
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
-      TAMF_LAUNCH_LOCK;
-      g_wg_slots_dev[device & 63] = 2 * cus;
-    }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      g_wg_slots_dev[device & 63].store(2 * cus, std::memory_order_relaxed);
   }
   hipError_t pe;
   {
-    TAMF_LAUNCH_LOCK;  // prepare() keeps unsynchronised per-device "done" flags that locked launches read
+    TAMF_STATE_LOCK;  // (one context at a time sets the kernel attributes of a device: they are idempotent, this only avoids the duplicate work)
     pe = prepare_all<OpF32>();
     if (pe == hipSuccess && precision != TAMF_PREC_F32) TAMF_WITH_OP(precision, pe = prepare_all<Op>());
   }

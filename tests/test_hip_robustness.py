@@ -92,6 +92,55 @@ def test_two_contexts_do_not_interfere():
     c2.close()
 
 
+def test_two_contexts_driven_from_two_threads():
+    """Round 6: the product library takes no process-wide lock any more (it guarded the kernel-selection word of tamf_set_gemm_tuning,
+    which now lives in the hooks build only).  Two contexts, two host threads, two streams, each thread running plain-launch and
+    hipGraph loops and single evaluations of its own context at the same time: every result equals the one the same context gives alone."""
+    import threading
+
+    from oracle import mdm_oracle as O
+    from test_hip_forward import _set_cond
+
+    arch = O.ARCH_TINY
+    sds = [O.det_state_dict(arch, tag="thr/a"), O.det_state_dict(arch, tag="thr/b")]
+    precs = ["f16x3", "bf16"]
+    ctxs = [_ctx(arch, sds[i], 3, 24, prec=precs[i], n_steps=40) for i in range(2)]
+    conds = [_cond(3, 24, f"thr/c{i}") for i in range(2)]
+    x = torch.randn(3, 99, 1, 24, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([4, 900, 17])
+    for c, cd in zip(ctxs, conds):
+        _set_cond(c, cd)
+    alone = [(c.sample_loop(seed=11 + i).cpu(), c.sample_loop(seed=11 + i, use_graph=False).cpu(), c.denoise(x, t).cpu()) for i, c in enumerate(ctxs)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    got, errs = [[], []], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    a = ctxs[i].sample_loop(seed=11 + i)
+                    b = ctxs[i].sample_loop(seed=11 + i, use_graph=False)
+                    c = ctxs[i].denoise(x, t)
+                    streams[i].synchronize()
+                    got[i].append((a.cpu(), b.cpu(), c.cpu()))
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for w in th:
+        w.start()
+    for w in th:
+        w.join()
+    assert not errs, errs
+    for i in range(2):
+        assert len(got[i]) == 6
+        for a, b, c in got[i]:
+            assert torch.equal(a, alone[i][0]) and torch.equal(b, alone[i][1]) and torch.equal(c, alone[i][2]), i
+        assert torch.equal(alone[i][0], alone[i][1])  # (graph == plain launches)
+    for c in ctxs:
+        c.close()
+
+
 def test_ddpm_step_entry_point():
     """tamf_ddpm_step reproduces the oracle's float32 arithmetic (same op order, no FMA contraction); the only source of
     difference is the last bit of sigma = exp(0.5 * logvar) (libm expf vs torch.exp), hence 1e-6 instead of bit equality;
