@@ -15,5 +15,5 @@ for d in ("full", "r100"):
     print(d, len(fs), a.shape, a.dtype, "finite", bool(np.isfinite(a).all()), "mean |x|", float(np.abs(a).mean()))
 PY
 } > gpurun_out/r06/cli_respacing_c16.txt 2>&1
-rm -rf gpurun_out/r06/cli
+cd ../../.. && rm -rf gpurun_out/r06/cli
 cat gpurun_out/r06/cli_respacing_c16.txt
